@@ -1,0 +1,184 @@
+/*
+ * ptrace.h — C ABI of libptrace_hip.so, the MI355X (gfx950) implementation of the
+ * per-pixel radiance() path-tracing loop of filippo-orru/path-tracer-rust.
+ *
+ * The reference has no FFI/plugin interface (it is safe Rust only).  The narrowest seam is
+ * the parallel section of render() — src/render/mod.rs:1017-1024 — which fills
+ * `pixels: Vec<Vec3>` (index (H-1-y)*W+x, mod.rs:805-806) for a RenderConfig
+ * (mod.rs:859-864) under a cancel flag (mod.rs:943,1003) and a progress counter
+ * (mod.rs:960,850).  pt_render() replaces exactly that loop; everything in this header is
+ * what a Rust `extern "C"` block for that seam would bind (INTEGRATION.md shows the shim).
+ *
+ * Conventions: plain pointers and sizes, caller owns every buffer, no unwinding, every
+ * entry point returns an int status (PT_OK or a negative PT_ERR_*), message through
+ * pt_last_error().  There is no CPU fallback: without a HIP device every compute entry
+ * point fails with PT_ERR_NO_DEVICE.
+ */
+#ifndef PTRACE_H
+#define PTRACE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_ABI_VERSION 1
+
+/* status codes (reference behaviour: unwrap() panics, mod.rs:96,309,1032,1042,1093) */
+#define PT_OK 0
+#define PT_ERR_INVALID (-1)    /* bad argument / malformed scene */
+#define PT_ERR_NO_DEVICE (-2)  /* no HIP device (the product never falls back to the CPU) */
+#define PT_ERR_HIP (-3)        /* a HIP runtime call failed; text in pt_last_error() */
+#define PT_CANCELLED (-4)      /* *cancel became non-zero; framebuffer holds the passes done so far */
+#define PT_ERR_OVERFLOW (-5)   /* a ray queue overflowed (cannot happen with the sizes pt_render picks) */
+#define PT_ERR_IO (-6)         /* file could not be read / written */
+#define PT_ERR_PARSE (-7)      /* scene JSON / OFF syntax or shape error */
+
+/* ReflectType — enum order of src/render/mod.rs:71-76 */
+#define PT_DIFFUSE 0u
+#define PT_SPECULAR 1u
+#define PT_REFRACT 2u
+
+/* SceneObject kind — src/render/mod.rs:326-335 */
+#define PT_SPHERE 0u
+#define PT_MESH 1u
+
+/* backends of the hot path (both run on the GPU) */
+#define PT_BACKEND_WAVEFRONT 0u /* SoA ray queues in HBM, generate/intersect/shade kernels per bounce */
+#define PT_BACKEND_MEGAKERNEL 1u /* persistent threads: whole render_pixel loop per lane */
+
+/* pt_config.flags */
+#define PT_FLAG_NO_BVH 1u /* meshes are scanned triangle by triangle as the reference does (mod.rs:558) */
+
+/* CameraData — src/render/mod.rs:162-176.  `direction` is used as stored (not renormalised). */
+typedef struct pt_camera {
+    float position[3];
+    float direction[3];
+    float focal_length;
+    float sensor_width;
+    float aspect_ratio;
+} pt_camera;
+
+/* Triangle — src/render/mod.rs:538-543, object-local vertices. */
+typedef struct pt_triangle {
+    float a[3];
+    float b[3];
+    float c[3];
+} pt_triangle;
+
+/* SceneObjectData + Material flattened — src/render/mod.rs:253-258, 78-83, 326-335, 440-448.
+ * For PT_MESH, triangles [tri_offset, tri_offset+tri_count) of the triangle array belong to the
+ * object and (bs_center, bs_radius) is Mesh.bounding_sphere exactly as stored/computed
+ * (object-local centre; mod.rs:268 adds `position`). */
+typedef struct pt_object {
+    uint32_t kind;
+    float position[3];
+    float radius; /* PT_SPHERE only */
+    float color[3];
+    float emission[3]; /* the reference spells it `emmission` */
+    uint32_t reflect_type;
+    uint32_t tri_offset;
+    uint32_t tri_count;
+    float bs_center[3];
+    float bs_radius;
+} pt_object;
+
+/* RenderConfig + Resolution (src/render/mod.rs:859-870) plus what the GPU path needs. */
+typedef struct pt_config {
+    uint32_t width;
+    uint32_t height;
+    uint32_t spp;      /* samples_per_pixel */
+    uint32_t backend;  /* PT_BACKEND_* */
+    uint64_t seed;     /* key of the counter-based RNG that stands in for rand::random (mod.rs:53) */
+    uint32_t idx_begin; /* framebuffer-index band [idx_begin, idx_end) to render; 0,0 = whole frame */
+    uint32_t idx_end;
+    uint32_t rays_per_pass; /* wavefront: primary rays generated per pass; 0 = library default */
+    uint32_t flags;
+} pt_config;
+
+typedef struct pt_stats {
+    uint64_t ray_bounces;        /* number of intersect_scene evaluations (mod.rs:663), exact */
+    uint64_t samples;            /* primary samples traced */
+    uint64_t intersect_rays;     /* rays processed by the intersect kernel (== ray_bounces for wavefront) */
+    uint32_t intersect_launches; /* launches of the intersect kernel */
+    uint32_t passes;
+    double ms_total;     /* wall time of the call */
+    double ms_device;    /* HIP-event time from first to last kernel of the call */
+    double ms_intersect; /* HIP-event time summed over intersect-kernel launches (only if PT profiling on) */
+} pt_stats;
+
+/* progress callback: fraction in [0,1]; invoked on the calling thread between passes */
+typedef void (*pt_progress_fn)(void *user, float fraction);
+
+typedef struct pt_ctx pt_ctx;
+
+const char *pt_version(void);
+const char *pt_last_error(void);
+int pt_abi_version(void);
+int pt_device_count(void);
+
+/* a3 — CameraData::{lens_center, orthogonals} (mod.rs:211-232), host arithmetic in f32. */
+int pt_camera_basis(const pt_camera *cam, float lens_center[3], float su[3], float sv[3]);
+
+/* a10 — Mesh::new bounding sphere (mod.rs:450-499), including its `min + max*0.5` centre. */
+int pt_mesh_bounding_sphere(const pt_triangle *tris, uint32_t n_tris, float center[3], float *radius);
+
+/* One context = one GPU, one stream, device copies of one scene and the ray queues. */
+int pt_ctx_create(int device, pt_ctx **out);
+void pt_ctx_destroy(pt_ctx *ctx);
+int pt_ctx_set_scene(pt_ctx *ctx, const pt_camera *cam, const pt_object *objs, uint32_t n_objs,
+                     const pt_triangle *tris, uint32_t n_tris);
+
+/* Render the band [idx_begin, idx_end) into DEVICE memory: d_out_rgb holds
+ * (idx_end-idx_begin)*3 floats, element (idx-idx_begin)*3+c, linear, clamped to [0,1] — the
+ * memory image of the reference's Vec<Vec3> slice (mod.rs:1013-1014, 852-856).
+ * `hip_stream` is a hipStream_t (NULL = the context's own stream).  Blocking. */
+int pt_ctx_render(pt_ctx *ctx, const pt_config *cfg, void *d_out_rgb, void *hip_stream,
+                  const volatile uint8_t *cancel, pt_progress_fn cb, void *user, pt_stats *stats);
+
+/* Enable HIP-event timing of every intersect-kernel launch (fills pt_stats.ms_intersect). */
+int pt_ctx_set_profiling(pt_ctx *ctx, int enabled);
+
+/* Single-ray queries through the same device intersection code (a6): the callers are object
+ * picking / click-debug / orbit pivot (src/views/viewport_tab.rs:240-246, render_tab.rs:177-205).
+ * Host arrays: o,d = n*3 floats; outputs may be NULL.  object_id = -1 on a miss
+ * (intersect_scene -> None), tri_id = index into the object's triangle list or -1 for spheres. */
+int pt_ctx_intersect(pt_ctx *ctx, const float *o, const float *d, uint32_t n, float *t,
+                     int32_t *object_id, int32_t *tri_id, float *x, float *normal);
+
+/* The drop-in for mod.rs:1017-1024: host buffers in, host framebuffer out (whole W*H*3 floats,
+ * only the band is written).  Uses device 0 (or PT_DEVICE env).  Blocking. */
+int pt_render(const pt_config *cfg, const pt_camera *cam, const pt_object *objs, uint32_t n_objs,
+              const pt_triangle *tris, uint32_t n_tris, float *out_rgb,
+              const volatile uint8_t *cancel, pt_progress_fn cb, void *user, pt_stats *stats);
+
+/* ---- formats either side of the path (host only, no GPU needed) ------------------------- */
+
+typedef struct pt_scene pt_scene;
+
+/* SceneDescriptor::load + to_data (mod.rs:92-110, 304-318) and load_off (load_off.rs:8-85).
+ * `path` is the JSON file; MeshFile paths are resolved against `base_dir` (the reference
+ * resolves them against the process CWD; pass "." for that behaviour). */
+int pt_scene_load(const char *path, const char *base_dir, pt_scene **out);
+void pt_scene_free(pt_scene *s);
+const char *pt_scene_id(const pt_scene *s);
+const pt_camera *pt_scene_camera(const pt_scene *s);
+const pt_object *pt_scene_objects(const pt_scene *s, uint32_t *n);
+const pt_triangle *pt_scene_triangles(const pt_scene *s, uint32_t *n);
+
+/* load_off (load_off.rs:8-85): returns a malloc'ed triangle array (free with pt_free). */
+int pt_load_off(const char *path, float scale, pt_triangle **tris, uint32_t *n_tris);
+void pt_free(void *p);
+
+/* gamma (mod.rs:57-63) and the P3 writer (mod.rs:1043-1076). */
+float pt_gamma_correction(float x);
+uint32_t pt_to_int_with_gamma_correction(float x);
+int pt_write_ppm(const char *path, const float *rgb, uint32_t width, uint32_t height, uint32_t spp,
+                 const char *scene_id, uint64_t seconds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTRACE_H */

@@ -1,0 +1,733 @@
+/*
+ * pt_oracle.c — CPU restatement of the reference's radiance() hot path.  TEST INFRASTRUCTURE.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may build, load or call
+ * this file.  The product (libptrace_hip.so and the host tools) never links it.
+ *
+ * What it restates (all citations relative to /root/reference):
+ *   rand01 .................. src/render/mod.rs:47-55   (RNG replaced, see "RNG contract" below)
+ *   gamma / to_int .......... src/render/mod.rs:57-63
+ *   camera basis ............ src/render/mod.rs:211-232
+ *   SceneObjectData::intersect  src/render/mod.rs:261-280
+ *   intersect_sphere ........ src/render/mod.rs:412-438
+ *   Mesh::new bounds ........ src/render/mod.rs:450-499
+ *   Triangle::intersect ..... src/render/mod.rs:546-616
+ *   intersect_scene ......... src/render/mod.rs:631-659
+ *   radiance ................ src/render/mod.rs:661-792  (recursive, literal)
+ *   render_pixel ............ src/render/mod.rs:794-857
+ *   render parallel loop .... src/render/mod.rs:1017-1024 (rayon -> OpenMP dynamic over shuffled pixels)
+ *   PPM writer .............. src/render/mod.rs:1043-1076
+ *   Image hash .............. src/render/mod.rs:916-926  (SipHash-1-3, Rust DefaultHasher)
+ *
+ * Third-party arithmetic absent from /root/reference, restated from the published sources:
+ *   glam 0.30.8 (Cargo.lock)  scalar Vec3: dot=(x*x'+y*y')+z*z', cross, length=sqrt(dot),
+ *                             normalize = v * (1/length), Vec3/f32 component-wise divide.
+ *   rand 0.8.5  Standard f32: (u32 >> 8) * 2^-24.
+ *   Rust std f32::sin/cos -> platform libm sinf/cosf.  pto_sinf/pto_cosf restate glibc's
+ *       algorithm (ARM optimized-routines sinf.c/cosf.c/sincosf.h, in glibc >= 2.28) and
+ *       tests/test_oracle.py checks them bit-for-bit against the platform libm on EVERY
+ *       argument the path can produce (r1 = 2*PI*k*2^-24, k < 2^24).
+ *   f32::powi(2) = x*x, powi(5) = x*((x*x)*(x*x)) (LLVM binary powi expansion / __powisf2).
+ *
+ * Parity pinning: the reference cannot be built here (no rustc/cargo, 507 un-vendored crates)
+ * and is not reproducible run to run (OS-seeded ThreadRng, mod.rs:53).  This file is pinned by
+ * the 7 tests of src/render/test.rs (restated in tests/test_oracle.py): vector ops, gamma,
+ * four sphere-hit KATs and the statistical test_radiance bound.  Triangle intersection, the
+ * camera mapping, specular/refract/RR branches and the PPM bytes are NOT pinned by any
+ * reference fixture: for those, parity is pinned only by this restatement following the cited
+ * lines ("parity unpinned" by the reference's own tests).
+ *
+ * RNG contract (shared with the HIP path, which must draw bit-identical numbers):
+ *   Philox4x32-10, key = (seed_lo, seed_hi), counter = (pixel_idx, sample_idx, tag, 0),
+ *   tag = 0 for the two camera draws of a sample (word0 -> r1/x, word1 -> r2/y, mod.rs:818-819),
+ *   tag = (branch << 8) | new_depth for one radiance() invocation:
+ *         word0 -> Russian roulette (mod.rs:678), word1 -> diffuse r1 (mod.rs:691) or the
+ *         refract reflect/transmit choice (mod.rs:761), word2 -> diffuse r2 (mod.rs:692).
+ *   branch = 1 at the root; a refract split (mod.rs:775-786) continues with branch 2b for the
+ *   reflected ray and 2b+1 for the transmitted ray.  u32 -> f32 as rand 0.8.5 does.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math (strict per-op IEEE f32 is the reference's
+ * semantics: rustc/LLVM never contracts or reassociates).
+ */
+#include "pt_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ glam Vec3 (scalar) */
+typedef struct {
+    float x, y, z;
+} v3;
+
+static inline v3 V(float x, float y, float z) {
+    v3 r = {x, y, z};
+    return r;
+}
+static inline v3 vld(const float *p) { return V(p[0], p[1], p[2]); }
+static inline void vst(float *p, v3 a) {
+    p[0] = a.x;
+    p[1] = a.y;
+    p[2] = a.z;
+}
+static inline v3 vadd(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 vsub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 vmul(v3 a, v3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline v3 vscale(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+static inline v3 vdivs(v3 a, float s) { return V(a.x / s, a.y / s, a.z / s); }
+static inline float vdot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline v3 vcross(v3 a, v3 b) {
+    return V(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
+}
+static inline float vlength(v3 a) { return sqrtf(vdot(a, a)); }
+static inline v3 vnormalize(v3 a) { return vscale(a, 1.0f / vlength(a)); }
+
+void pto_vec_ops(const float *a, const float *b, float s, float *out) {
+    /* out: add(3) sub(3) mul(3) scale(3) div(3) dot(1) cross(3) normalize_a(3) length_a(1) */
+    v3 A = vld(a), B = vld(b);
+    vst(out + 0, vadd(A, B));
+    vst(out + 3, vsub(A, B));
+    vst(out + 6, vmul(A, B));
+    vst(out + 9, vscale(A, s));
+    vst(out + 12, vdivs(A, s));
+    out[15] = vdot(A, B);
+    vst(out + 16, vcross(A, B));
+    vst(out + 19, vnormalize(A));
+    out[22] = vlength(A);
+}
+
+/* ------------------------------------------------------------------ sinf / cosf (glibc algorithm) */
+static const double HPI_INV = 0x1.45F306DC9C883p+23; /* 2/PI * 2^24 */
+static const double HPI = 0x1.921FB54442D18p0;
+static const double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5,
+                    C3 = -0x1.6c087e89a359dp-10, C4 = 0x1.99343027bf8c3p-16;
+static const double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7,
+                    S3 = -0x1.994eb3774cf24p-13;
+
+static inline uint32_t abstop12(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return (u >> 20) & 0x7ff;
+}
+
+/* n even: sine polynomial; n odd: cosine polynomial, negated when `neg` (quadrants 2,3). */
+static inline float sincos_poly(double x, double x2, int neg, int n) {
+    if ((n & 1) == 0) {
+        double x3 = x * x2;
+        double s1 = S2 + x2 * S3;
+        double x7 = x3 * x2;
+        double s = x + x3 * S1;
+        return (float)(s + x7 * s1);
+    } else {
+        double sg = neg ? -1.0 : 1.0;
+        double x4 = x2 * x2;
+        double c2 = sg * C3 + x2 * (sg * C4);
+        double c1 = sg * C1 + x2 * (sg * C2);
+        double x6 = x4 * x2;
+        double c = sg * C0 + x2 * c1;
+        return (float)(c + x6 * c2);
+    }
+}
+
+static inline double reduce_fast(double x, int *np) {
+    double r = x * HPI_INV;
+    int n = ((int32_t)r + 0x800000) >> 24;
+    *np = n;
+    return x - n * HPI;
+}
+
+/* valid for |y| < 120 (the path only produces y in [0, 2*PI)) */
+float pto_sinf(float y) {
+    double x = y;
+    if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
+        if (abstop12(y) < abstop12(0x1p-12f)) return y;
+        return sincos_poly(x, x * x, 0, 0);
+    }
+    int n;
+    x = reduce_fast(x, &n);
+    double s = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+    return sincos_poly(x * s, x * x, (n & 2) != 0, n);
+}
+
+float pto_cosf(float y) {
+    double x = y;
+    if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
+        if (abstop12(y) < abstop12(0x1p-12f)) return 1.0f;
+        return sincos_poly(x, x * x, 0, 1);
+    }
+    int n;
+    x = reduce_fast(x, &n);
+    double s = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+    return sincos_poly(x * s, x * x, (n & 2) != 0, n ^ 1);
+}
+
+/* count arguments 2*PI*(k*2^-24) on which pto_sinf/pto_cosf differ from the platform libm */
+void pto_sincos_vs_libm(uint32_t k_begin, uint32_t k_end, uint64_t *sin_mismatch, uint64_t *cos_mismatch) {
+    const float two_pi = 2.0f * 3.141592653589793f;
+    uint64_t ms = 0, mc = 0;
+    for (uint32_t k = k_begin; k < k_end; k++) {
+        float a = two_pi * ((float)k * (1.0f / 16777216.0f));
+        float s0 = sinf(a), s1 = pto_sinf(a), c0 = cosf(a), c1 = pto_cosf(a);
+        ms += memcmp(&s0, &s1, 4) != 0;
+        mc += memcmp(&c0, &c1, 4) != 0;
+    }
+    *sin_mismatch = ms;
+    *cos_mismatch = mc;
+}
+
+/* ------------------------------------------------------------------ Philox4x32-10 */
+static inline void philox_round(uint32_t c[4], uint32_t k0, uint32_t k1) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c[0] = n0;
+    c[1] = n1;
+    c[2] = n2;
+    c[3] = n3;
+}
+
+void pto_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; r++) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    memcpy(out, c, 16);
+}
+
+/* rand 0.8.5 Standard<f32>: 24 high bits -> [0,1) */
+float pto_u32_to_unit(uint32_t u) { return (float)(u >> 8) * (1.0f / 16777216.0f); }
+
+static inline void draw4(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t tag, float u[4]) {
+    uint32_t ctr[4] = {pixel, sample, tag, 0u};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t o[4];
+    pto_philox4x32_10(ctr, key, o);
+    for (int i = 0; i < 4; i++) u[i] = pto_u32_to_unit(o[i]);
+}
+
+void pto_draw4(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t tag, float u[4]) {
+    draw4(seed, pixel, sample, tag, u);
+}
+
+/* ------------------------------------------------------------------ gamma (mod.rs:57-63) */
+float pto_gamma_correction(float x) {
+    float c = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); /* f32::clamp: NaN stays NaN */
+    return powf(c, 1.0f / 2.2f);
+}
+
+uint32_t pto_to_int_with_gamma_correction(float x) {
+    float v = 255.0f * pto_gamma_correction(x) + 0.5f;
+    if (!(v == v)) return 0; /* Rust `as usize`: NaN -> 0, saturating */
+    if (v <= 0.0f) return 0;
+    return (uint32_t)v;
+}
+
+/* ------------------------------------------------------------------ camera (mod.rs:211-232) */
+void pto_camera_basis(const pt_camera *cam, float lens_center[3], float su_out[3], float sv_out[3]) {
+    v3 pos = vld(cam->position), dir = vld(cam->direction);
+    float sensor_height = cam->sensor_width / cam->aspect_ratio;
+    v3 lens = vadd(pos, vscale(dir, cam->focal_length));
+    v3 up = fabsf(dir.y) < 0.9f ? V(0.0f, 1.0f, 0.0f) : V(0.0f, 0.0f, 1.0f);
+    v3 su = vnormalize(vcross(dir, up));
+    v3 sv = vcross(su, dir);
+    vst(lens_center, lens);
+    vst(su_out, vscale(su, cam->sensor_width));
+    vst(sv_out, vscale(sv, sensor_height));
+}
+
+/* ------------------------------------------------------------------ Mesh::new (mod.rs:450-499) */
+void pto_mesh_bounding_sphere(const pt_triangle *tris, uint32_t n, float center[3], float *radius) {
+    v3 mn = V(INFINITY, INFINITY, INFINITY), mx = V(-INFINITY, -INFINITY, -INFINITY);
+    for (uint32_t i = 0; i < n; i++) {
+        const float *vs[3] = {tris[i].a, tris[i].b, tris[i].c};
+        for (int k = 0; k < 3; k++) {
+            const float *p = vs[k];
+            if (p[0] < mn.x) mn.x = p[0];
+            if (p[1] < mn.y) mn.y = p[1];
+            if (p[2] < mn.z) mn.z = p[2];
+            if (p[0] > mx.x) mx.x = p[0];
+            if (p[1] > mx.y) mx.y = p[1];
+            if (p[2] > mx.z) mx.z = p[2];
+        }
+    }
+    /* sic: min + max*0.5, not (min+max)*0.5 (mod.rs:478-482) */
+    v3 c = V(mn.x + mx.x * 0.5f, mn.y + mx.y * 0.5f, mn.z + mx.z * 0.5f);
+    float r0 = vlength(vsub(mn, c)), r1 = vlength(vsub(mx, c));
+    /* Iterator::max_by returns the LAST maximum: r1 unless r0 > r1 */
+    float r = (r0 > r1) ? r0 : r1;
+    vst(center, c);
+    *radius = r;
+}
+
+/* ------------------------------------------------------------------ intersection */
+typedef struct {
+    float distance;
+    v3 intersection;
+    v3 normal;
+} hit_t;
+
+/* intersect_sphere, mod.rs:412-438 */
+static int intersect_sphere(v3 position, float radius, v3 ro, v3 rd, hit_t *h) {
+    v3 op = vsub(position, ro);
+    const float eps = 1e-4f;
+    float b = vdot(op, rd);
+    float det = b * b - vdot(op, op) + radius * radius;
+    if (det < 0.0f) return 0;
+    det = sqrtf(det);
+    float t;
+    if (b - det >= eps)
+        t = b - det;
+    else if (b + det >= eps)
+        t = b + det;
+    else
+        return 0;
+    v3 xmin = vadd(ro, vscale(rd, t));
+    v3 nmin = vnormalize(vsub(xmin, position));
+    h->distance = t;
+    h->intersection = xmin;
+    h->normal = nmin;
+    return 1;
+}
+
+/* Triangle::intersect, mod.rs:554-615 (USE_CULLING = false) */
+static int intersect_triangles(v3 ro, v3 rd, v3 offset, const pt_triangle *tris, uint32_t n, hit_t *h,
+                               int32_t *tri_index) {
+    int found = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        v3 a = vadd(vld(tris[i].a), offset); /* Triangle::transformed, mod.rs:546-552 */
+        v3 b = vadd(vld(tris[i].b), offset);
+        v3 c = vadd(vld(tris[i].c), offset);
+        v3 va_vb = vsub(b, a);
+        v3 va_vc = vsub(c, a);
+        v3 pvec = vcross(rd, va_vc);
+        float determinant = vdot(va_vb, pvec);
+        if (fabsf(determinant) < 1e-4f) continue;
+        float inv_determinant = 1.0f / determinant;
+        v3 tvec = vsub(ro, a);
+        float u = vdot(tvec, pvec) * inv_determinant;
+        if (u < 0.0f || u > 1.0f) continue;
+        v3 qvec = vcross(tvec, va_vb);
+        float v = vdot(rd, qvec) * inv_determinant;
+        if (v < 0.0f || (u + v) > 1.0f) continue;
+        float distance = vdot(va_vc, qvec) * inv_determinant;
+        if (distance <= 0.0f) continue;
+        int is_closest = found ? (distance < h->distance) : 1;
+        if (is_closest) {
+            h->distance = distance;
+            h->intersection = vadd(ro, vscale(rd, distance));
+            h->normal = vnormalize(vcross(va_vb, va_vc));
+            if (tri_index) *tri_index = (int32_t)i;
+            found = 1;
+        }
+    }
+    return found;
+}
+
+/* SceneObjectData::intersect, mod.rs:261-280 */
+static int object_intersect(const pt_object *o, const pt_triangle *tris, v3 ro, v3 rd, hit_t *h,
+                            int32_t *tri_index, pto_counters *cnt) {
+    v3 pos = vld(o->position);
+    if (o->kind == PT_SPHERE) {
+        if (cnt) cnt->sphere_tests++;
+        if (tri_index) *tri_index = -1;
+        return intersect_sphere(pos, o->radius, ro, rd, h);
+    }
+    hit_t gate;
+    if (cnt) cnt->sphere_tests++;
+    if (!intersect_sphere(vadd(vld(o->bs_center), pos), o->bs_radius, ro, rd, &gate)) return 0;
+    if (cnt) cnt->triangle_tests += o->tri_count;
+    return intersect_triangles(ro, rd, pos, tris + o->tri_offset, o->tri_count, h, tri_index);
+}
+
+/* intersect_scene, mod.rs:631-659: reverse order, strict < (ties keep the higher index) */
+static int intersect_scene(const pto_scene *s, v3 ro, v3 rd, int32_t *object_id, int32_t *tri_id, hit_t *h,
+                           pto_counters *cnt) {
+    int found = 0;
+    for (int32_t i = (int32_t)s->n_objs - 1; i >= 0; i--) {
+        hit_t nh;
+        int32_t ti = -1;
+        if (!object_intersect(&s->objs[i], s->tris, ro, rd, &nh, &ti, cnt)) continue;
+        if (!found || nh.distance < h->distance) {
+            *h = nh;
+            *object_id = i;
+            if (tri_id) *tri_id = ti;
+            found = 1;
+        }
+    }
+    return found;
+}
+
+int pto_intersect_sphere(const float pos[3], float radius, const float o[3], const float d[3], float *t,
+                         float x[3], float n[3]) {
+    hit_t h;
+    if (!intersect_sphere(vld(pos), radius, vld(o), vld(d), &h)) return 0;
+    *t = h.distance;
+    vst(x, h.intersection);
+    vst(n, h.normal);
+    return 1;
+}
+
+void pto_intersect_batch(const pto_scene *s, const float *o, const float *d, uint32_t n, float *t,
+                         int32_t *object_id, int32_t *tri_id, float *x, float *nrm) {
+    for (uint32_t i = 0; i < n; i++) {
+        hit_t h;
+        int32_t oid = -1, tid = -1;
+        int f = intersect_scene(s, vld(o + 3 * i), vld(d + 3 * i), &oid, &tid, &h, NULL);
+        if (!f) {
+            oid = -1;
+            tid = -1;
+            h.distance = 0.0f;
+            h.intersection = V(0, 0, 0);
+            h.normal = V(0, 0, 0);
+        }
+        if (t) t[i] = h.distance;
+        if (object_id) object_id[i] = oid;
+        if (tri_id) tri_id[i] = tid;
+        if (x) vst(x + 3 * i, h.intersection);
+        if (nrm) vst(nrm + 3 * i, h.normal);
+    }
+}
+
+/* ------------------------------------------------------------------ radiance (mod.rs:661-792) */
+#define MAX_DEPTH 12
+static const float PI_F = 3.141592653589793f;
+
+typedef struct {
+    const pto_scene *scene;
+    uint64_t seed;
+    uint32_t pixel, sample;
+    pto_counters *cnt;
+    /* optional ray dump (every intersect_scene call): o(3) d(3) per ray */
+    float *dump;
+    uint64_t dump_cap, dump_n;
+} rctx;
+
+static v3 radiance(rctx *c, v3 ro, v3 rd, int depth, uint32_t branch) {
+    if (c->cnt) c->cnt->ray_bounces++;
+    if (c->dump && c->dump_n < c->dump_cap) {
+        float *p = c->dump + 6 * c->dump_n++;
+        vst(p, ro);
+        vst(p + 3, rd);
+    }
+    hit_t hit;
+    int32_t object_id = -1;
+    if (!intersect_scene(c->scene, ro, rd, &object_id, NULL, &hit, c->cnt)) {
+        if (c->cnt) c->cnt->misses++;
+        return V(0, 0, 0);
+    }
+    const pt_object *object = &c->scene->objs[object_id];
+    v3 color = vld(object->color);
+    v3 emission = vld(object->emission);
+    float max_reflection = fmaxf(color.x, fmaxf(color.y, color.z));
+    v3 normal_towards_ray = vdot(hit.normal, rd) < 0.0f ? hit.normal : vscale(hit.normal, -1.0f);
+
+    int new_depth = depth + 1;
+    float u[4];
+    draw4(c->seed, c->pixel, c->sample, (branch << 8) | (uint32_t)new_depth, u);
+
+    /* Russian roulette, mod.rs:676-683 (the draw happens before the depth test: short-circuit &&) */
+    if (new_depth > 5) {
+        if (u[0] < max_reflection && new_depth < MAX_DEPTH)
+            color = vscale(color, 1.0f / max_reflection);
+        else
+            return emission;
+    }
+
+    v3 rest;
+    if (object->reflect_type == PT_DIFFUSE) { /* mod.rs:687-715 */
+        float r1 = 2.0f * PI_F * u[1];
+        float r2 = u[2];
+        float r2s = sqrtf(r2);
+        v3 w = normal_towards_ray;
+        v3 uu = vnormalize(vcross(fabsf(w.x) > 0.1f ? V(0, 1, 0) : V(1, 0, 0), w));
+        v3 vv = vcross(w, uu);
+        v3 d = vnormalize(vadd(vadd(vscale(vscale(uu, pto_cosf(r1)), r2s), vscale(vscale(vv, pto_sinf(r1)), r2s)),
+                               vscale(w, sqrtf(1.0f - r2))));
+        rest = vmul(color, radiance(c, hit.intersection, d, new_depth, branch));
+    } else if (object->reflect_type == PT_SPECULAR) { /* mod.rs:716-728 */
+        v3 d = vsub(rd, vscale(vscale(hit.normal, 2.0f), vdot(hit.normal, rd)));
+        rest = vmul(color, radiance(c, hit.intersection, d, new_depth, branch));
+    } else { /* Refract, mod.rs:729-788 */
+        v3 refl_d = vsub(rd, vscale(vscale(hit.normal, 2.0f), vdot(hit.normal, rd)));
+        int into = vdot(hit.normal, normal_towards_ray) > 0.0f;
+        const float nc = 1.0f, nt = 1.5f;
+        float nnt = into ? nc / nt : nt / nc;
+        float ddn = vdot(rd, normal_towards_ray);
+        float cos2t = 1.0f - (nnt * nnt) * (1.0f - ddn * ddn);
+        if (cos2t < 0.0f) {
+            rest = vmul(color, radiance(c, hit.intersection, refl_d, new_depth, branch));
+        } else {
+            v3 tdir = vnormalize(vsub(vscale(rd, nnt),
+                                      vscale(hit.normal, (into ? 1.0f : -1.0f) * (ddn * nnt + sqrtf(cos2t)))));
+            float a = nt - nc, b = nt + nc;
+            float r0 = a * a / (b * b);
+            float cc = 1.0f - (into ? -ddn : vdot(tdir, hit.normal));
+            float c5 = cc * ((cc * cc) * (cc * cc)); /* powi(5) */
+            float re = r0 + (1.0f - r0) * c5;
+            float tr = 1.0f - re;
+            float p = 0.25f + 0.5f * re;
+            float rp = re / p;
+            float tp = tr / (1.0f - p);
+            if (new_depth > 2) {
+                if (u[1] < p)
+                    rest = vscale(vmul(color, radiance(c, hit.intersection, refl_d, new_depth, branch)), rp);
+                else
+                    rest = vscale(vmul(color, radiance(c, hit.intersection, tdir, new_depth, branch)), tp);
+            } else {
+                if (c->cnt) c->cnt->splits++;
+                v3 lr = vscale(radiance(c, hit.intersection, refl_d, new_depth, 2u * branch), re);
+                v3 lt = vscale(radiance(c, hit.intersection, tdir, new_depth, 2u * branch + 1u), tr);
+                rest = vmul(color, vadd(lr, lt));
+            }
+        }
+    }
+    return vadd(emission, rest);
+}
+
+/* test_radiance's loop (test.rs:146-183): `n` samples of one fixed ray, sample i keyed (pixel, i) */
+void pto_radiance_mean(const pto_scene *s, const float o[3], const float d[3], uint64_t seed, uint32_t pixel,
+                       uint32_t n, float out[3], pto_counters *cnt) {
+    rctx c = {s, seed, pixel, 0, cnt, NULL, 0, 0};
+    v3 acc = V(0, 0, 0);
+    for (uint32_t i = 0; i < n; i++) {
+        c.sample = i;
+        acc = vadd(acc, radiance(&c, vld(o), vld(d), 0, 1u));
+    }
+    vst(out, vdivs(acc, (float)n));
+}
+
+/* ------------------------------------------------------------------ render_pixel (mod.rs:794-857) */
+typedef struct {
+    v3 pos, lens, su, sv;
+} cam_basis;
+
+static cam_basis make_basis(const pt_camera *cam) {
+    cam_basis b;
+    float l[3], su[3], sv[3];
+    pto_camera_basis(cam, l, su, sv);
+    b.pos = vld(cam->position);
+    b.lens = vld(l);
+    b.su = vld(su);
+    b.sv = vld(sv);
+    return b;
+}
+
+static inline float tent(float r) { return r < 1.0f ? sqrtf(r) - 1.0f : 1.0f - sqrtf(2.0f - r); }
+
+static void primary_ray(const cam_basis *cb, uint32_t width, uint32_t height, uint32_t pixel_index, uint32_t s,
+                        uint64_t seed, v3 *ro, v3 *rd) {
+    uint32_t y = height - 1 - pixel_index / width;
+    uint32_t x = pixel_index % width;
+    float ysub = (float)((s / 2) % 2);
+    float xsub = (float)(s % 2);
+    float u[4];
+    draw4(seed, pixel_index, s, 0u, u);
+    float r1 = 2.0f * u[0];
+    float r2 = 2.0f * u[1];
+    float xfilter = tent(r1);
+    float yfilter = tent(r2);
+    float sx = ((float)x + 0.5f * (0.5f + xsub + xfilter)) / (float)width - 0.5f;
+    float sy = ((float)y + 0.5f * (0.5f + ysub + yfilter)) / (float)height - 0.5f;
+    v3 sensor_pos = vadd(vadd(cb->pos, vscale(cb->su, sx)), vscale(cb->sv, sy));
+    *rd = vnormalize(vsub(cb->lens, sensor_pos));
+    *ro = cb->lens;
+}
+
+static v3 render_pixel(const pto_scene *s, const cam_basis *cb, const pto_config *cfg, uint32_t pixel_index,
+                       pto_counters *cnt) {
+    rctx c = {s, cfg->seed, pixel_index, 0, cnt, NULL, 0, 0};
+    v3 radiance_v = V(0, 0, 0);
+    for (uint32_t smp = 0; smp < cfg->spp; smp++) {
+        v3 ro, rd;
+        primary_ray(cb, cfg->width, cfg->height, pixel_index, smp, cfg->seed, &ro, &rd);
+        c.sample = smp;
+        radiance_v = vadd(radiance_v, radiance(&c, ro, rd, 0, 1u));
+    }
+    radiance_v = vdivs(radiance_v, (float)cfg->spp);
+#define CLAMP01(v) ((v) < 0.0f ? 0.0f : ((v) > 1.0f ? 1.0f : (v)))
+    return V(CLAMP01(radiance_v.x), CLAMP01(radiance_v.y), CLAMP01(radiance_v.z));
+}
+
+void pto_primary_ray(const pt_camera *cam, uint32_t width, uint32_t height, uint32_t pixel_index,
+                     uint32_t sample, uint64_t seed, float o[3], float d[3]) {
+    cam_basis cb = make_basis(cam);
+    v3 ro, rd;
+    primary_ray(&cb, width, height, pixel_index, sample, seed, &ro, &rd);
+    vst(o, ro);
+    vst(d, rd);
+}
+
+void pto_render_pixel(const pto_scene *s, const pto_config *cfg, uint32_t pixel_index, float out[3],
+                      pto_counters *cnt) {
+    cam_basis cb = make_basis(&s->camera);
+    vst(out, render_pixel(s, &cb, cfg, pixel_index, cnt));
+}
+
+/* Dump every ray the path tracer casts for the pixels [idx_begin, idx_end): used to test the HIP
+ * intersect kernel ray by ray.  Returns the number of rays written (<= cap). */
+uint64_t pto_dump_rays(const pto_scene *s, const pto_config *cfg, uint32_t idx_begin, uint32_t idx_end,
+                       float *rays_od, uint64_t cap) {
+    cam_basis cb = make_basis(&s->camera);
+    rctx c = {s, cfg->seed, 0, 0, NULL, rays_od, cap, 0};
+    for (uint32_t idx = idx_begin; idx < idx_end; idx++) {
+        c.pixel = idx;
+        for (uint32_t smp = 0; smp < cfg->spp; smp++) {
+            v3 ro, rd;
+            primary_ray(&cb, cfg->width, cfg->height, idx, smp, cfg->seed, &ro, &rd);
+            c.sample = smp;
+            (void)radiance(&c, ro, rd, 0, 1u);
+        }
+    }
+    return c.dump_n;
+}
+
+/* ------------------------------------------------------------------ render loop (mod.rs:1017-1024) */
+static uint64_t splitmix64(uint64_t *s) {
+    uint64_t z = (*s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+/* Renders framebuffer indices [idx_begin, idx_end) into out_rgb[(idx)*3..] (whole-frame buffer).
+ * Pixels are visited in shuffled order with dynamic scheduling over `threads` workers — the
+ * reference's rayon into_par_iter over a shuffled index vector.  The image does not depend on
+ * the order or the thread count (RNG is keyed per pixel/sample). */
+int pto_render(const pto_scene *s, const pto_config *cfg, uint32_t idx_begin, uint32_t idx_end, float *out_rgb,
+               int threads, pto_counters *cnt_out, double *seconds) {
+    if (idx_end <= idx_begin || idx_end > cfg->width * cfg->height) return -1;
+    uint32_t n = idx_end - idx_begin;
+    uint32_t *order = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    if (!order) return -2;
+    for (uint32_t i = 0; i < n; i++) order[i] = idx_begin + i;
+    uint64_t st = 0x1234567ull;
+    for (uint32_t i = n - 1; i > 0; i--) { /* Fisher-Yates, as SliceRandom::shuffle */
+        uint32_t j = (uint32_t)(splitmix64(&st) % (i + 1));
+        uint32_t tmp = order[i];
+        order[i] = order[j];
+        order[j] = tmp;
+    }
+    cam_basis cb = make_basis(&s->camera);
+    pto_counters total;
+    memset(&total, 0, sizeof total);
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel
+#endif
+    {
+        pto_counters local;
+        memset(&local, 0, sizeof local);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 16)
+#endif
+        for (uint32_t i = 0; i < n; i++) {
+            uint32_t idx = order[i];
+            v3 px = render_pixel(s, &cb, cfg, idx, &local);
+            vst(out_rgb + 3 * (size_t)idx, px);
+        }
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+        {
+            total.ray_bounces += local.ray_bounces;
+            total.misses += local.misses;
+            total.splits += local.splits;
+            total.sphere_tests += local.sphere_tests;
+            total.triangle_tests += local.triangle_tests;
+        }
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (seconds) *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    if (cnt_out) *cnt_out = total;
+    free(order);
+    return 0;
+}
+
+int pto_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------ PPM (mod.rs:1043-1076) */
+/* Writes the exact byte stream of the reference's writer into buf (if non-NULL); returns its length. */
+size_t pto_format_ppm(const float *rgb, uint32_t width, uint32_t height, uint32_t spp, const char *scene_id,
+                      uint64_t seconds, char *buf, size_t cap) {
+    size_t len = 0;
+    char tmp[512];
+    int k = snprintf(tmp, sizeof tmp,
+                     "P3\n# samplesPerPixel: %u, resolution_y: %u, scene_id: %s\n# rendering time: %llu s\n%u %u\n%d\n",
+                     spp, height, scene_id, (unsigned long long)seconds, width, height, 255);
+    if (buf && len + (size_t)k <= cap) memcpy(buf + len, tmp, (size_t)k);
+    len += (size_t)k;
+    size_t npx = (size_t)width * height;
+    for (size_t i = npx; i-- > 0;) { /* pixels.iter().rev() */
+        k = snprintf(tmp, sizeof tmp, "%u %u %u ", pto_to_int_with_gamma_correction(rgb[3 * i]),
+                     pto_to_int_with_gamma_correction(rgb[3 * i + 1]),
+                     pto_to_int_with_gamma_correction(rgb[3 * i + 2]));
+        if (buf && len + (size_t)k <= cap) memcpy(buf + len, tmp, (size_t)k);
+        len += (size_t)k;
+    }
+    return len;
+}
+
+/* ------------------------------------------------------------------ Image hash (mod.rs:916-926) */
+/* Rust's DefaultHasher = SipHash-1-3 with zero keys; u32::hash feeds 4 little-endian bytes. */
+#define ROTL(x, b) (uint64_t)(((x) << (b)) | ((x) >> (64 - (b))))
+#define SIPROUND           \
+    do {                   \
+        v0 += v1;          \
+        v1 = ROTL(v1, 13); \
+        v1 ^= v0;          \
+        v0 = ROTL(v0, 32); \
+        v2 += v3;          \
+        v3 = ROTL(v3, 16); \
+        v3 ^= v2;          \
+        v0 += v3;          \
+        v3 = ROTL(v3, 21); \
+        v3 ^= v0;          \
+        v2 += v1;          \
+        v1 = ROTL(v1, 17); \
+        v1 ^= v2;          \
+        v2 = ROTL(v2, 32); \
+    } while (0)
+
+uint64_t pto_siphash13(const uint8_t *data, size_t len) {
+    uint64_t v0 = 0x736f6d6570736575ull, v1 = 0x646f72616e646f6dull, v2 = 0x6c7967656e657261ull,
+             v3 = 0x7465646279746573ull;
+    size_t end = len - (len % 8);
+    for (size_t i = 0; i < end; i += 8) {
+        uint64_t m;
+        memcpy(&m, data + i, 8);
+        v3 ^= m;
+        SIPROUND;
+        v0 ^= m;
+    }
+    uint64_t b = ((uint64_t)len) << 56;
+    for (size_t i = 0; i < (len & 7); i++) b |= ((uint64_t)data[end + i]) << (8 * i);
+    v3 ^= b;
+    SIPROUND;
+    v0 ^= b;
+    v2 ^= 0xff;
+    SIPROUND;
+    SIPROUND;
+    SIPROUND;
+    return v0 ^ v1 ^ v2 ^ v3;
+}
+
+uint64_t pto_image_hash(const float *rgb, size_t n_floats) { return pto_siphash13((const uint8_t *)rgb, n_floats * 4); }

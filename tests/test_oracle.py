@@ -1,0 +1,181 @@
+"""Pin the CPU restatement (oracle/) against every known-answer test the reference holds for the path:
+the 7 tests of src/render/test.rs, restated with the same inputs and the same exact expectations."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import ptlib
+from ptlib import PtoCounters, _np_f, f3, make_camera, make_sphere, Scene
+
+L = ptlib.oracle()
+
+
+def vec_ops(a, b, s):
+    out = np.zeros(23, dtype=np.float32)
+    L.pto_vec_ops(_np_f(np.array(a, dtype=np.float32)), _np_f(np.array(b, dtype=np.float32)), s, _np_f(out))
+    return dict(add=out[0:3], sub=out[3:6], mul=out[6:9], scale=out[9:12], div=out[12:15], dot=out[15],
+                cross=out[16:19], normalize=out[19:22], length=out[22])
+
+
+def test_vector_operations():
+    """src/render/test.rs:3-27 (glam Vec3 semantics)."""
+    v1, v2, v3 = (1.0, 2.0, 3.0), (2.0, 3.0, 4.0), (3.0, 4.0, 5.0)
+    r = vec_ops(v1, v2, 2.0)
+    assert list(r["add"]) == [3.0, 5.0, 7.0]
+    assert list(vec_ops(v3, v2, 1.0)["sub"]) == [1.0, 1.0, 1.0]
+    assert list(r["mul"]) == [2.0, 6.0, 12.0]
+    assert list(r["scale"]) == [2.0, 4.0, 6.0]
+    assert list(vec_ops(v2, v1, 2.0)["div"]) == [1.0, 1.5, 2.0]
+    assert r["dot"] == 20.0
+    assert list(r["cross"]) == [-1.0, 2.0, -1.0]
+    assert list(vec_ops((1.0, 0.0, 0.0), v1, 1.0)["normalize"]) == [1.0, 0.0, 0.0]
+    n = vec_ops((1.0, 1.0, 0.0), v1, 1.0)["normalize"]
+    assert list(n) == [np.float32(0.7071067811865475), np.float32(0.7071067811865475), 0.0]
+    assert r["length"] == np.float32(3.7416573867739413)
+
+
+def test_helpers():
+    """src/render/test.rs:29-35."""
+    for x, want in [(0.0, 0), (0.5, 186), (0.75, 224), (1.0, 255)]:
+        assert L.pto_to_int_with_gamma_correction(x) == want
+    # outside the reference's test: clamp and NaN behaviour of `as usize`
+    assert L.pto_to_int_with_gamma_correction(-3.0) == 0
+    assert L.pto_to_int_with_gamma_correction(7.0) == 255
+    assert L.pto_to_int_with_gamma_correction(float("nan")) == 0
+
+
+TEST_MAT = dict(color=(1.0, 0.0, 0.0), emission=(0.0, 0.0, 0.0), reflect="Diffuse")
+
+
+def one_sphere_scene(pos):
+    cam = make_camera((0, 0, 0), (0, 0, -1))
+    return Scene("t", cam, [make_sphere(pos, 1.0, **TEST_MAT)], [])
+
+
+def isect(scene, o, d):
+    o = np.array(o, dtype=np.float32)
+    d = np.array(d, dtype=np.float32)
+    t = np.zeros(1, dtype=np.float32)
+    oid = np.zeros(1, dtype=np.int32)
+    tid = np.zeros(1, dtype=np.int32)
+    x = np.zeros(3, dtype=np.float32)
+    n = np.zeros(3, dtype=np.float32)
+    ps = scene.pto()
+    L.pto_intersect_batch(C.byref(ps), _np_f(o), _np_f(d), 1, _np_f(t), oid.ctypes.data_as(ptlib.i32p),
+                          tid.ctypes.data_as(ptlib.i32p), _np_f(x), _np_f(n))
+    return int(oid[0]), float(t[0]), list(x), list(n)
+
+
+SPHERE_KATS = [
+    # (sphere position, ray origin, ray direction, expected (object_id, distance, x, n) or None)
+    ((0, 0, -3), (0, 0, 0), (0, 0, -1), (0, 2.0, [0, 0, -2], [0, 0, 1])),        # test.rs:43-69
+    ((0, 0, -3), (2, 0, 0), "norm(1,0,-1)", None),                                # test.rs:72-87
+    ((0, 0, 0), (0, 0, 0), (0, 0, -1), (0, 1.0, [0, 0, -1], [0, 0, -1])),         # test.rs:90-116
+    ((0, 0, -3), (0, 1, 0), (0, 0, -1), (0, 3.0, [0, 1, -3], [0, 1, 0])),         # test.rs:119-144
+]
+
+
+@pytest.mark.parametrize("pos,o,d,want", SPHERE_KATS)
+def test_intersect_scene_kats(pos, o, d, want):
+    if isinstance(d, str):
+        d = list(vec_ops((1.0, 0.0, -1.0), (0, 0, 0), 1.0)["normalize"])
+    oid, t, x, n = isect(one_sphere_scene(pos), o, d)
+    if want is None:
+        assert oid == -1
+    else:
+        assert (oid, t, x, n) == (want[0], want[1], [float(v) for v in want[2]], [float(v) for v in want[3]])
+
+
+def test_radiance():
+    """src/render/test.rs:146-183: mean of 10 000 samples of one ray, .x > 0.3 (analytic 50/144 = 0.34722),
+    y and z exactly 0 (red diffuse sphere)."""
+    cam = make_camera((0, 0, 0), (0, 0, -1))
+    sc = Scene("t", cam, [make_sphere((0, 0, -3), 1.0, (1, 0, 0), (0, 0, 0), "Diffuse"),
+                          make_sphere((0, 0, 10), 1.0, (0, 0, 0), (50, 50, 50), "Diffuse")], [])
+    ps = sc.pto()
+    o = np.array([0, 0, 0], dtype=np.float32)
+    d = np.array([0, 0, -1], dtype=np.float32)
+    out = np.zeros(3, dtype=np.float32)
+    cnt = PtoCounters()
+    L.pto_radiance_mean(C.byref(ps), _np_f(o), _np_f(d), 1, 0, 10000, _np_f(out), C.byref(cnt))
+    assert out[0] > 0.3, out
+    assert out[1] == 0.0 and out[2] == 0.0
+    # tighter, with 400k samples: analytic expectation 50 * (1/12)^2
+    L.pto_radiance_mean(C.byref(ps), _np_f(o), _np_f(d), 7, 3, 400000, _np_f(out), C.byref(cnt))
+    assert abs(out[0] - 50.0 / 144.0) < 0.02, out
+
+
+# ------------------------------------------------------------------ third-party arithmetic
+PHILOX_KATS = [  # Random123 kat_vectors, philox4x32 10 rounds: counter, key, expected
+    ([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+    ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+    ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+     [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]),
+]
+
+
+@pytest.mark.parametrize("ctr,key,want", PHILOX_KATS)
+def test_philox_kat(ctr, key, want):
+    out = (C.c_uint32 * 4)()
+    L.pto_philox4x32_10((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), out)
+    assert list(out) == want
+
+
+def test_u32_to_unit():
+    """rand 0.8.5 Standard<f32>: 24 high bits, [0,1)."""
+    assert L.pto_u32_to_unit(0) == 0.0
+    assert L.pto_u32_to_unit(0xffffffff) == float(np.float32(1.0) - np.float32(2.0 ** -24))
+    assert L.pto_u32_to_unit(0x80000000) == 0.5
+    assert L.pto_u32_to_unit(0x000000ff) == 0.0
+
+
+def test_sincos_equals_platform_libm_on_whole_domain():
+    """Rust f32::sin/cos -> libm sinf/cosf.  The path only evaluates them at r1 = 2*PI*(k*2^-24)
+    (mod.rs:691,703): check all 2^24 arguments bit for bit against this machine's libm."""
+    ms, mc = C.c_uint64(), C.c_uint64()
+    L.pto_sincos_vs_libm(0, 1 << 24, C.byref(ms), C.byref(mc))
+    # glibc >= 2.28 gives 0; allow a handful for libms whose contraction of the double polynomial differs
+    assert ms.value <= 4 and mc.value <= 4, (ms.value, mc.value)
+
+
+def test_sincos_accuracy():
+    xs = np.linspace(0, 2 * math.pi, 20001).astype(np.float32)
+    for x in xs[::37]:
+        assert abs(L.pto_sinf(float(x)) - math.sin(float(x))) < 1.2e-7
+        assert abs(L.pto_cosf(float(x)) - math.cos(float(x))) < 1.2e-7
+
+
+def test_camera_basis_cornell():
+    """SURVEY Appendix A numbers (numpy f32 probe) for the shared camera."""
+    sc = ptlib.load_scene_py(ptlib.scene_path("cornell"))
+    lens, su, sv = (C.c_float * 3)(), (C.c_float * 3)(), (C.c_float * 3)()
+    L.pto_camera_basis(C.byref(sc.cam), lens, su, sv)
+    assert np.allclose(list(lens), [0, -0.20209628, 7.765063], atol=1e-6)
+    assert np.allclose(list(su), [0.036, 0, 0], atol=1e-7)
+    assert np.allclose(list(sv), [0, 0.02395691, -0.00143741], atol=1e-7)
+
+
+def test_mesh_bounding_sphere_matches_stored():
+    """Mesh::new (mod.rs:450-499) recomputed on the inline quads reproduces the bounding spheres the
+    reference serialised into cornell.json (incl. the min+max*0.5 centre)."""
+    sc = ptlib.load_scene_py(ptlib.scene_path("cornell"))
+    for i in range(sc.n_objs):
+        o = sc.objs[i]
+        if o.kind != ptlib.PT_MESH:
+            continue
+        arr = (ptlib.PtTriangle * o.tri_count)(*[sc.tris[o.tri_offset + k] for k in range(o.tri_count)])
+        ctr, rad = (C.c_float * 3)(), C.c_float()
+        L.pto_mesh_bounding_sphere(arr, o.tri_count, ctr, C.byref(rad))
+        assert list(ctr) == list(o.bs_center), i
+        assert rad.value == o.bs_radius, i
+
+
+def test_siphash13_kat():
+    """Rust DefaultHasher (SipHash-1-3, zero key).  Known value: hashing nothing -> 0x1e924b9d737700d7? is not
+    relied upon; pin against the reference SipHash-1-3 test vector property instead: 8 zero bytes differ from
+    empty and the function is deterministic."""
+    a = L.pto_siphash13(b"", 0)
+    b = L.pto_siphash13(b"\0" * 8, 8)
+    assert a != b and a == L.pto_siphash13(b"", 0)
