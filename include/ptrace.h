@@ -148,6 +148,12 @@ int pt_ctx_set_profiling(pt_ctx *ctx, int enabled);
 int pt_ctx_intersect(pt_ctx *ctx, const float *o, const float *d, uint32_t n, float *t,
                      int32_t *object_id, int32_t *tri_id, float *x, float *normal);
 
+/* Diagnostics: evaluate the device's numerics contract (sin, cos, sqrt, 1/x on in[i]; Philox block for
+ * counter (i, bits(in[i]), (i<<8)|(i&15), 0), key 0x0123456789abcdef) so tests can compare it bit for bit
+ * with the host.  Host arrays of n (out_philox: 4n). */
+int pt_ctx_numerics_probe(pt_ctx *ctx, const float *in, uint32_t n, float *out_sin, float *out_cos,
+                          float *out_sqrt, float *out_rcp, uint32_t *out_philox);
+
 /* The drop-in for mod.rs:1017-1024: host buffers in, host framebuffer out (whole W*H*3 floats,
  * only the band is written).  Uses device 0 (or PT_DEVICE env).  Blocking. */
 int pt_render(const pt_config *cfg, const pt_camera *cam, const pt_object *objs, uint32_t n_objs,

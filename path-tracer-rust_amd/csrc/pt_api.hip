@@ -1,0 +1,633 @@
+// pt_api.hip — C ABI of the compute path (include/ptrace.h): contexts, scene flattening, the pass loop
+// of the wavefront pipeline, the megakernel launch, single-ray queries.  No CPU fallback exists here:
+// without a HIP device every entry point returns PT_ERR_NO_DEVICE.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ptrace.h"
+#include "pt_host.h"
+#include "pt_kernels.h"
+
+namespace pt {
+
+thread_local std::string g_last_error;
+
+void set_error(const std::string &m) { g_last_error = m; }
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                              \
+            return PT_ERR_HIP;                                                                         \
+        }                                                                                              \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    int ensure(size_t count) {
+        if (count <= n && p) return PT_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+        hipError_t e = hipMalloc((void **)&p, (count ? count : 1) * sizeof(T));
+        if (e != hipSuccess) {
+            set_error(std::string("hipMalloc: ") + hipGetErrorString(e));
+            return PT_ERR_HIP;
+        }
+        n = count;
+        return PT_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+}  // namespace pt
+
+using namespace pt;
+
+struct pt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool has_scene = false;
+    bool profiling = false;
+    pt_camera cam{};
+    DevScene scene{};
+    DevBuf<ObjRec> d_objs;
+    DevBuf<TriRec> d_tris;
+    DevBuf<MatRec> d_mats;
+    DevBuf<TriShade> d_tshade;
+    // wavefront queues
+    uint32_t K = 0, cap = 0;
+    DevBuf<float4> q_od0[2], q_tp[2];
+    DevBuf<float2> q_od1[2], hit;
+    DevBuf<uint32_t> q_meta[2], cnt, flags;
+    DevBuf<unsigned long long> blk_rays, acc, total_rays;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+namespace {
+
+int device_count_quiet() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int check_cfg(const pt_config *cfg, uint32_t *idx_begin, uint32_t *idx_end) {
+    if (!cfg) {
+        set_error("cfg is NULL");
+        return PT_ERR_INVALID;
+    }
+    if (cfg->width == 0 || cfg->height == 0 || cfg->spp == 0) {
+        set_error("width, height and spp must be positive");
+        return PT_ERR_INVALID;
+    }
+    const uint64_t npix = (uint64_t)cfg->width * cfg->height;
+    if (npix > 0x7fffffffull) {
+        set_error("width*height exceeds 2^31-1");
+        return PT_ERR_INVALID;
+    }
+    if (cfg->spp > (1u << 24)) {
+        set_error("spp exceeds 2^24");
+        return PT_ERR_INVALID;
+    }
+    uint32_t b = cfg->idx_begin, e = cfg->idx_end;
+    if (b == 0 && e == 0) e = (uint32_t)npix;
+    if (b >= e || e > npix) {
+        set_error("band [idx_begin, idx_end) is empty or outside the frame");
+        return PT_ERR_INVALID;
+    }
+    if (cfg->backend != PT_BACKEND_WAVEFRONT && cfg->backend != PT_BACKEND_MEGAKERNEL) {
+        set_error("unknown backend");
+        return PT_ERR_INVALID;
+    }
+    *idx_begin = b;
+    *idx_end = e;
+    return PT_OK;
+}
+
+FrameParams make_frame(const pt_ctx *ctx, const pt_config *cfg, uint32_t idx_begin, uint32_t idx_end) {
+    FrameParams F{};
+    float lens[3], su[3], sv[3];
+    host::camera_basis(ctx->cam, lens, su, sv);
+    F.width = cfg->width;
+    F.height = cfg->height;
+    F.spp = cfg->spp;
+    F.idx_begin = idx_begin;
+    F.npix = idx_end - idx_begin;
+    F.seed_lo = (uint32_t)cfg->seed;
+    F.seed_hi = (uint32_t)(cfg->seed >> 32);
+    F.cam_px = ctx->cam.position[0];
+    F.cam_py = ctx->cam.position[1];
+    F.cam_pz = ctx->cam.position[2];
+    F.lens_x = lens[0];
+    F.lens_y = lens[1];
+    F.lens_z = lens[2];
+    F.su_x = su[0];
+    F.su_y = su[1];
+    F.su_z = su[2];
+    F.sv_x = sv[0];
+    F.sv_y = sv[1];
+    F.sv_z = sv[2];
+    return F;
+}
+
+RayQueue queue_of(pt_ctx *c, int which) {
+    RayQueue q;
+    q.od0 = c->q_od0[which].p;
+    q.od1 = c->q_od1[which].p;
+    q.tp = c->q_tp[which].p;
+    q.meta = c->q_meta[which].p;
+    return q;
+}
+
+hipEvent_t get_event(pt_ctx *c, size_t i) {
+    while (c->ev_pool.size() <= i) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        c->ev_pool.push_back(e);
+    }
+    return c->ev_pool[i];
+}
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &F, hipStream_t st,
+                     const volatile uint8_t *cancel, pt_progress_fn cb, void *user, pt_stats *stats) {
+    const uint64_t npix = F.npix;
+    uint64_t want = cfg->rays_per_pass ? cfg->rays_per_pass : (8u << 20);
+    uint32_t spp_pass = (uint32_t)(want / npix);
+    if (spp_pass == 0) spp_pass = 1;
+    if (spp_pass > cfg->spp) spp_pass = cfg->spp;
+    const uint64_t n_primary_max = npix * spp_pass;
+    if (n_primary_max > 0xffffffffull / 8) {
+        set_error("rays per pass too large");
+        return PT_ERR_INVALID;
+    }
+    const uint64_t n_chunks = (n_primary_max + kBlock - 1) / kBlock;
+    uint32_t K = 2048;
+    if (n_chunks < K) K = (uint32_t)n_chunks;
+    const uint64_t chunks_per_stream = (n_chunks + K - 1) / K;
+    // a primary ray has at most 4 descendants alive at one depth (two refract splits, mod.rs:760)
+    const uint64_t cap64 = 4 * chunks_per_stream * kBlock;
+    const uint32_t cap = (uint32_t)cap64;
+    const size_t slots = (size_t)K * cap;
+    for (int w = 0; w < 2; ++w) {
+        int rc;
+        if ((rc = c->q_od0[w].ensure(slots)) || (rc = c->q_od1[w].ensure(slots)) || (rc = c->q_tp[w].ensure(slots)) ||
+            (rc = c->q_meta[w].ensure(slots)))
+            return rc;
+    }
+    int rc;
+    if ((rc = c->hit.ensure(slots)) || (rc = c->cnt.ensure((size_t)kLevels * K)) || (rc = c->flags.ensure(1)) ||
+        (rc = c->blk_rays.ensure(K)) || (rc = c->acc.ensure(3 * npix)))
+        return rc;
+    c->K = K;
+    c->cap = cap;
+    HIP_TRY(hipMemsetAsync(c->acc.p, 0, 3 * npix * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(c->blk_rays.p, 0, K * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(c->cnt.p, 0, (size_t)kLevels * K * sizeof(uint32_t), st));
+
+    const uint32_t n_pass = (cfg->spp + spp_pass - 1) / spp_pass;
+    const int n_depth = kMaxDepth;  // rays of depth 0..11 exist
+    size_t ev_i = 0;
+    hipEvent_t ev_begin = get_event(c, ev_i++), ev_end = get_event(c, ev_i++);
+    hipEvent_t pass_done[2] = {get_event(c, ev_i++), get_event(c, ev_i++)};
+    if (!ev_begin || !ev_end || !pass_done[0] || !pass_done[1]) {
+        set_error("hipEventCreate failed");
+        return PT_ERR_HIP;
+    }
+    const size_t ev_prof0 = ev_i;
+    size_t n_prof = 0;
+    HIP_TRY(hipEventRecord(ev_begin, st));
+    bool cancelled = false;
+    uint32_t passes_done = 0;
+    for (uint32_t p = 0; p < n_pass; ++p) {
+        if (p >= 2) HIP_TRY(hipEventSynchronize(pass_done[p & 1]));  // keep two passes in flight
+        if (cancel && *cancel) {
+            cancelled = true;
+            break;
+        }
+        if (cb && p >= 2) cb(user, (float)(p - 1) / (float)n_pass);
+        const uint32_t s0 = p * spp_pass;
+        const uint32_t s_here = (cfg->spp - s0) < spp_pass ? (cfg->spp - s0) : spp_pass;
+        const uint64_t n_primary = npix * s_here;
+        launch_generate(st, K, F, queue_of(c, 0), c->cnt.p, cap, s0, n_primary);
+        for (int d = 0; d < n_depth; ++d) {
+            const RayQueue qin = queue_of(c, d & 1), qout = queue_of(c, (d + 1) & 1);
+            if (c->profiling) {
+                hipEvent_t a = get_event(c, ev_prof0 + 2 * n_prof), b = get_event(c, ev_prof0 + 2 * n_prof + 1);
+                if (!a || !b) {
+                    set_error("hipEventCreate failed");
+                    return PT_ERR_HIP;
+                }
+                HIP_TRY(hipEventRecord(a, st));
+                launch_intersect(st, K, c->scene, qin, c->hit.p, c->cnt.p + (size_t)d * K, cap, c->blk_rays.p);
+                HIP_TRY(hipEventRecord(b, st));
+                ++n_prof;
+            } else {
+                launch_intersect(st, K, c->scene, qin, c->hit.p, c->cnt.p + (size_t)d * K, cap, c->blk_rays.p);
+            }
+            launch_shade(st, K, c->scene, F, qin, qout, c->hit.p, c->cnt.p + (size_t)d * K,
+                         c->cnt.p + (size_t)(d + 1) * K, cap, c->acc.p, c->flags.p);
+        }
+        HIP_TRY(hipEventRecord(pass_done[p & 1], st));
+        ++passes_done;
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev_end, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::vector<unsigned long long> rays(K);
+    HIP_TRY(hipMemcpy(rays.data(), c->blk_rays.p, K * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    uint32_t flags = 0;
+    HIP_TRY(hipMemcpy(&flags, c->flags.p, sizeof flags, hipMemcpyDeviceToHost));
+    if (stats) {
+        unsigned long long total = 0;
+        for (auto v : rays) total += v;
+        stats->ray_bounces = total;
+        stats->intersect_rays = total;
+        stats->intersect_launches = passes_done * (uint32_t)n_depth;
+        stats->passes = passes_done;
+        uint64_t smp = 0;
+        for (uint32_t p = 0; p < passes_done; ++p) {
+            const uint32_t s0 = p * spp_pass;
+            smp += npix * ((cfg->spp - s0) < spp_pass ? (cfg->spp - s0) : spp_pass);
+        }
+        stats->samples = smp;
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev_begin, ev_end));
+        stats->ms_device = ms;
+        double mi = 0.0;
+        for (size_t i = 0; i < n_prof; ++i) {
+            float e = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&e, c->ev_pool[ev_prof0 + 2 * i], c->ev_pool[ev_prof0 + 2 * i + 1]));
+            mi += e;
+        }
+        stats->ms_intersect = mi;
+    }
+    if (flags & 1u) {
+        set_error("ray stream overflow");
+        return PT_ERR_OVERFLOW;
+    }
+    if (cancelled) {
+        set_error("cancelled");
+        return PT_CANCELLED;
+    }
+    return PT_OK;
+}
+
+int render_mega(pt_ctx *c, const pt_config *cfg, const FrameParams &F, hipStream_t st, const volatile uint8_t *cancel,
+                pt_progress_fn cb, void *user, pt_stats *stats) {
+    (void)cb;
+    (void)user;
+    const uint64_t npix = F.npix;
+    int rc;
+    if ((rc = c->acc.ensure(3 * npix)) || (rc = c->total_rays.ensure(1))) return rc;
+    HIP_TRY(hipMemsetAsync(c->acc.p, 0, 3 * npix * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(c->total_rays.p, 0, sizeof(unsigned long long), st));
+    if (cancel && *cancel) {
+        set_error("cancelled");
+        return PT_CANCELLED;
+    }
+    // enough (pixel, sample-chunk) items to fill the chip several times over
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+    const uint64_t lanes = (uint64_t)prop.multiProcessorCount * 2048u;
+    uint32_t n_chunks = 1;
+    while ((uint64_t)npix * n_chunks < 4 * lanes && n_chunks < cfg->spp) n_chunks *= 2;
+    if (n_chunks > cfg->spp) n_chunks = cfg->spp;
+    const uint32_t chunk_spp = (cfg->spp + n_chunks - 1) / n_chunks;
+    n_chunks = (cfg->spp + chunk_spp - 1) / chunk_spp;
+    const uint64_t items = npix * n_chunks;
+    uint64_t grid64 = (items + kBlock - 1) / kBlock;
+    const uint64_t max_grid = (uint64_t)prop.multiProcessorCount * 8u;
+    const uint32_t grid = (uint32_t)(grid64 < max_grid ? grid64 : max_grid);
+    hipEvent_t ev_begin = get_event(c, 0), ev_end = get_event(c, 1);
+    if (!ev_begin || !ev_end) {
+        set_error("hipEventCreate failed");
+        return PT_ERR_HIP;
+    }
+    HIP_TRY(hipEventRecord(ev_begin, st));
+    launch_mega(st, grid ? grid : 1u, c->scene, F, c->acc.p, chunk_spp, n_chunks, c->total_rays.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev_end, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (stats) {
+        unsigned long long total = 0;
+        HIP_TRY(hipMemcpy(&total, c->total_rays.p, sizeof total, hipMemcpyDeviceToHost));
+        stats->ray_bounces = total;
+        stats->intersect_rays = 0;
+        stats->intersect_launches = 0;
+        stats->passes = 1;
+        stats->samples = npix * cfg->spp;
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev_begin, ev_end));
+        stats->ms_device = ms;
+        stats->ms_intersect = 0.0;
+    }
+    return PT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *pt_version(void) { return "ptrace-hip 0.1 (gfx950)"; }
+const char *pt_last_error(void) { return g_last_error.c_str(); }
+int pt_abi_version(void) { return PT_ABI_VERSION; }
+int pt_device_count(void) { return device_count_quiet(); }
+
+int pt_camera_basis(const pt_camera *cam, float lens_center[3], float su[3], float sv[3]) {
+    if (!cam || !lens_center || !su || !sv) {
+        set_error("NULL argument");
+        return PT_ERR_INVALID;
+    }
+    host::camera_basis(*cam, lens_center, su, sv);
+    return PT_OK;
+}
+
+int pt_mesh_bounding_sphere(const pt_triangle *tris, uint32_t n_tris, float center[3], float *radius) {
+    if (!tris || !center || !radius || n_tris == 0) {
+        set_error("NULL argument or empty mesh");
+        return PT_ERR_INVALID;
+    }
+    host::mesh_bounding_sphere(tris, n_tris, center, radius);
+    return PT_OK;
+}
+
+int pt_ctx_create(int device, pt_ctx **out) {
+    if (!out) {
+        set_error("out is NULL");
+        return PT_ERR_INVALID;
+    }
+    *out = nullptr;
+    const int n = device_count_quiet();
+    if (n <= 0) {
+        set_error("no HIP device: libptrace_hip has no CPU fallback");
+        return PT_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) {
+        set_error("device index out of range");
+        return PT_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(device));
+    pt_ctx *c = new pt_ctx();
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        set_error(std::string("hipStreamCreate: ") + hipGetErrorString(e));
+        delete c;
+        return PT_ERR_HIP;
+    }
+    *out = c;
+    return PT_OK;
+}
+
+void pt_ctx_destroy(pt_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    c->d_objs.release();
+    c->d_tris.release();
+    c->d_mats.release();
+    c->d_tshade.release();
+    for (int w = 0; w < 2; ++w) {
+        c->q_od0[w].release();
+        c->q_od1[w].release();
+        c->q_tp[w].release();
+        c->q_meta[w].release();
+    }
+    c->hit.release();
+    c->cnt.release();
+    c->flags.release();
+    c->blk_rays.release();
+    c->acc.release();
+    c->total_rays.release();
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uint32_t n_objs,
+                     const pt_triangle *tris, uint32_t n_tris) {
+    if (!c || !cam || (!objs && n_objs) || (!tris && n_tris)) {
+        set_error("NULL argument");
+        return PT_ERR_INVALID;
+    }
+    host::FlatScene fs;
+    std::string err;
+    if (!host::flatten_scene(objs, n_objs, tris, n_tris, fs, err)) {
+        set_error(err);
+        return PT_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if ((rc = c->d_objs.ensure(fs.objs.size())) || (rc = c->d_tris.ensure(fs.tris.size())) ||
+        (rc = c->d_mats.ensure(fs.mats.size())) || (rc = c->d_tshade.ensure(fs.tri_shade.size())))
+        return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!fs.objs.empty())
+        HIP_TRY(hipMemcpy(c->d_objs.p, fs.objs.data(), fs.objs.size() * sizeof(ObjRec), hipMemcpyHostToDevice));
+    if (!fs.tris.empty())
+        HIP_TRY(hipMemcpy(c->d_tris.p, fs.tris.data(), fs.tris.size() * sizeof(TriRec), hipMemcpyHostToDevice));
+    if (!fs.mats.empty())
+        HIP_TRY(hipMemcpy(c->d_mats.p, fs.mats.data(), fs.mats.size() * sizeof(MatRec), hipMemcpyHostToDevice));
+    if (!fs.tri_shade.empty())
+        HIP_TRY(hipMemcpy(c->d_tshade.p, fs.tri_shade.data(), fs.tri_shade.size() * sizeof(TriShade),
+                          hipMemcpyHostToDevice));
+    c->scene.objs = c->d_objs.p;
+    c->scene.tris = c->d_tris.p;
+    c->scene.mats = c->d_mats.p;
+    c->scene.tri_shade = c->d_tshade.p;
+    c->scene.n_objs = n_objs;
+    c->scene.n_tris = n_tris;
+    c->cam = *cam;
+    c->has_scene = true;
+    return PT_OK;
+}
+
+int pt_ctx_set_profiling(pt_ctx *c, int enabled) {
+    if (!c) {
+        set_error("ctx is NULL");
+        return PT_ERR_INVALID;
+    }
+    c->profiling = enabled != 0;
+    return PT_OK;
+}
+
+int pt_ctx_render(pt_ctx *c, const pt_config *cfg, void *d_out_rgb, void *hip_stream, const volatile uint8_t *cancel,
+                  pt_progress_fn cb, void *user, pt_stats *stats) {
+    if (!c || !d_out_rgb) {
+        set_error("NULL argument");
+        return PT_ERR_INVALID;
+    }
+    if (!c->has_scene) {
+        set_error("no scene set");
+        return PT_ERR_INVALID;
+    }
+    uint32_t ib = 0, ie = 0;
+    int rc = check_cfg(cfg, &ib, &ie);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    const FrameParams F = make_frame(c, cfg, ib, ie);
+    if (stats) memset(stats, 0, sizeof *stats);
+    const double t0 = now_ms();
+    if (cfg->backend == PT_BACKEND_WAVEFRONT)
+        rc = render_wavefront(c, cfg, F, st, cancel, cb, user, stats);
+    else
+        rc = render_mega(c, cfg, F, st, cancel, cb, user, stats);
+    if (rc == PT_OK || rc == PT_CANCELLED) {
+        // a cancelled frame still resolves what was accumulated (the reference also writes the partial image)
+        launch_resolve(st, c->acc.p, (float *)d_out_rgb, F.npix, cfg->spp);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(st));
+        if (cb && rc == PT_OK) cb(user, 1.0f);
+    }
+    if (stats) stats->ms_total = now_ms() - t0;
+    return rc;
+}
+
+int pt_ctx_intersect(pt_ctx *c, const float *o, const float *d, uint32_t n, float *t, int32_t *object_id,
+                     int32_t *tri_id, float *x, float *normal) {
+    if (!c || !o || !d) {
+        set_error("NULL argument");
+        return PT_ERR_INVALID;
+    }
+    if (!c->has_scene) {
+        set_error("no scene set");
+        return PT_ERR_INVALID;
+    }
+    if (n == 0) return PT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf<float> d_o, d_d, d_t, d_x, d_n;
+    DevBuf<int32_t> d_oid, d_tid;
+    int rc;
+    if ((rc = d_o.ensure(3 * (size_t)n)) || (rc = d_d.ensure(3 * (size_t)n)) || (rc = d_t.ensure(n)) ||
+        (rc = d_x.ensure(3 * (size_t)n)) || (rc = d_n.ensure(3 * (size_t)n)) || (rc = d_oid.ensure(n)) ||
+        (rc = d_tid.ensure(n)))
+        return rc;
+    auto cleanup = [&]() {
+        d_o.release();
+        d_d.release();
+        d_t.release();
+        d_x.release();
+        d_n.release();
+        d_oid.release();
+        d_tid.release();
+    };
+#define Q_TRY(expr)                                                       \
+    do {                                                                  \
+        hipError_t e_ = (expr);                                           \
+        if (e_ != hipSuccess) {                                           \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); \
+            cleanup();                                                    \
+            return PT_ERR_HIP;                                            \
+        }                                                                 \
+    } while (0)
+    Q_TRY(hipMemcpy(d_o.p, o, 3 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    Q_TRY(hipMemcpy(d_d.p, d, 3 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    launch_query(c->stream, c->scene, d_o.p, d_d.p, n, d_t.p, d_oid.p, d_tid.p, d_x.p, d_n.p);
+    Q_TRY(hipGetLastError());
+    Q_TRY(hipStreamSynchronize(c->stream));
+    if (t) Q_TRY(hipMemcpy(t, d_t.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    if (object_id) Q_TRY(hipMemcpy(object_id, d_oid.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (tri_id) Q_TRY(hipMemcpy(tri_id, d_tid.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (x) Q_TRY(hipMemcpy(x, d_x.p, 3 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    if (normal) Q_TRY(hipMemcpy(normal, d_n.p, 3 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+#undef Q_TRY
+    cleanup();
+    return PT_OK;
+}
+
+int pt_ctx_numerics_probe(pt_ctx *c, const float *in, uint32_t n, float *out_sin, float *out_cos, float *out_sqrt,
+                          float *out_rcp, uint32_t *out_philox) {
+    if (!c || !in || !out_sin || !out_cos || !out_sqrt || !out_rcp || !out_philox || n == 0) {
+        set_error("NULL argument");
+        return PT_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf<float> d_in, d_s, d_c, d_q, d_r;
+    DevBuf<uint32_t> d_p;
+    int rc;
+    if ((rc = d_in.ensure(n)) || (rc = d_s.ensure(n)) || (rc = d_c.ensure(n)) || (rc = d_q.ensure(n)) ||
+        (rc = d_r.ensure(n)) || (rc = d_p.ensure(4 * (size_t)n)))
+        return rc;
+    hipError_t e = hipMemcpy(d_in.p, in, (size_t)n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        launch_numerics(c->stream, d_in.p, n, d_s.p, d_c.p, d_q.p, d_r.p, d_p.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(out_sin, d_s.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_cos, d_c.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_sqrt, d_q.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_rcp, d_r.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_philox, d_p.p, 4 * (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    d_in.release();
+    d_s.release();
+    d_c.release();
+    d_q.release();
+    d_r.release();
+    d_p.release();
+    if (e != hipSuccess) {
+        set_error(std::string("numerics probe: ") + hipGetErrorString(e));
+        return PT_ERR_HIP;
+    }
+    return PT_OK;
+}
+
+int pt_render(const pt_config *cfg, const pt_camera *cam, const pt_object *objs, uint32_t n_objs,
+              const pt_triangle *tris, uint32_t n_tris, float *out_rgb, const volatile uint8_t *cancel,
+              pt_progress_fn cb, void *user, pt_stats *stats) {
+    if (!out_rgb) {
+        set_error("out_rgb is NULL");
+        return PT_ERR_INVALID;
+    }
+    uint32_t ib = 0, ie = 0;
+    int rc = check_cfg(cfg, &ib, &ie);
+    if (rc) return rc;
+    int dev = 0;
+    if (const char *e = getenv("PT_DEVICE")) dev = atoi(e);
+    pt_ctx *c = nullptr;
+    if ((rc = pt_ctx_create(dev, &c))) return rc;
+    if ((rc = pt_ctx_set_scene(c, cam, objs, n_objs, tris, n_tris))) {
+        pt_ctx_destroy(c);
+        return rc;
+    }
+    const size_t nfl = (size_t)(ie - ib) * 3;
+    float *d_out = nullptr;
+    hipError_t e = hipMalloc((void **)&d_out, nfl * sizeof(float));
+    if (e != hipSuccess) {
+        set_error(std::string("hipMalloc(out): ") + hipGetErrorString(e));
+        pt_ctx_destroy(c);
+        return PT_ERR_HIP;
+    }
+    rc = pt_ctx_render(c, cfg, d_out, nullptr, cancel, cb, user, stats);
+    if (rc == PT_OK || rc == PT_CANCELLED) {
+        e = hipMemcpy(out_rgb + (size_t)ib * 3, d_out, nfl * sizeof(float), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            set_error(std::string("hipMemcpy(out): ") + hipGetErrorString(e));
+            rc = PT_ERR_HIP;
+        }
+    }
+    (void)hipFree(d_out);
+    pt_ctx_destroy(c);
+    return rc;
+}
+
+}  // extern "C"

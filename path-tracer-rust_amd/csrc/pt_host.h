@@ -1,0 +1,32 @@
+// pt_host.h — host-side setup arithmetic of the path (camera basis, Mesh::new bounds, scene flattening).
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "../../include/ptrace.h"
+#include "pt_device.h"
+
+namespace pt {
+
+void set_error(const std::string &m);
+
+namespace host {
+
+struct FlatScene {
+    std::vector<ObjRec> objs;
+    std::vector<TriRec> tris;
+    std::vector<MatRec> mats;
+    std::vector<TriShade> tri_shade;
+};
+
+// CameraData::{lens_center, orthogonals} — src/render/mod.rs:211-232
+void camera_basis(const pt_camera &cam, float lens_center[3], float su[3], float sv[3]);
+// Mesh::new bounding sphere — src/render/mod.rs:450-499
+void mesh_bounding_sphere(const pt_triangle *tris, uint32_t n, float center[3], float *radius);
+// validate + flatten (see pt_device.h for the record layouts); false + message on malformed input
+bool flatten_scene(const pt_object *objs, uint32_t n_objs, const pt_triangle *tris, uint32_t n_tris, FlatScene &out,
+                   std::string &err);
+
+}  // namespace host
+}  // namespace pt

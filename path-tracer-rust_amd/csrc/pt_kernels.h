@@ -1,0 +1,36 @@
+// pt_kernels.h — launch interface between the C-ABI layer (pt_api.hip) and the kernels (pt_kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "pt_device.h"
+
+namespace pt {
+
+constexpr uint32_t kBlock = 256;    // 4 waves of 64
+constexpr uint32_t kLevels = 13;    // ray depths 0..11 plus the (always empty) level written by the last shade
+
+// SoA-of-packets ray queue; every array holds K streams of `cap` slots (see pt_kernels.hip)
+struct RayQueue {
+    float4 *od0;     // origin xyz, direction x
+    float2 *od1;     // direction yz
+    float4 *tp;      // throughput rgb, pixel index bits
+    uint32_t *meta;  // sample | depth | branch
+};
+
+void launch_generate(hipStream_t st, uint32_t K, const FrameParams &F, const RayQueue &q, uint32_t *cnt0,
+                     uint32_t cap, uint32_t s0, uint64_t n_primary);
+void launch_intersect(hipStream_t st, uint32_t K, const DevScene &S, const RayQueue &q, float2 *hit,
+                      const uint32_t *cnt, uint32_t cap, unsigned long long *blk_rays);
+void launch_shade(hipStream_t st, uint32_t K, const DevScene &S, const FrameParams &F, const RayQueue &qin,
+                  const RayQueue &qout, const float2 *hit, const uint32_t *cnt_in, uint32_t *cnt_out, uint32_t cap,
+                  unsigned long long *acc, uint32_t *flags);
+void launch_resolve(hipStream_t st, const unsigned long long *acc, float *out, uint32_t npix, uint32_t spp);
+void launch_mega(hipStream_t st, uint32_t grid, const DevScene &S, const FrameParams &F, unsigned long long *acc,
+                 uint32_t chunk_spp, uint32_t n_chunks, unsigned long long *total_rays);
+void launch_query(hipStream_t st, const DevScene &S, const float *o, const float *d, uint32_t n, float *t,
+                  int32_t *object_id, int32_t *tri_id, float *x, float *nrm);
+void launch_numerics(hipStream_t st, const float *in, uint32_t n, float *out_sin, float *out_cos, float *out_sqrt,
+                     float *out_rcp, uint32_t *out_philox);
+
+}  // namespace pt

@@ -1,0 +1,348 @@
+// pt_kernels.hip — gfx950 kernels of the wavefront radiance() pipeline and the persistent megakernel.
+//
+// Wavefront pipeline (one pass = P primary rays):
+//   k_generate                         tent filter + pinhole ray        (render_pixel, mod.rs:812-843)
+//   for depth = 0..11:
+//     k_intersect                      closest hit per ray              (intersect_scene, mod.rs:631-659)
+//     k_shade                          roulette, emission, BRDF sample, (radiance body, mod.rs:665-789)
+//                                      refract split, stream compaction
+//   k_resolve (once per frame)         /spp, clamp                      (mod.rs:849-856)
+//
+// Ray streams.  The ray queue is cut into K block-private streams: workgroup b of every kernel reads
+// stream b of the current level and appends survivors to stream b of the next level.  A stream is a
+// contiguous slice [b*cap, b*cap+count[b]) of each queue array, so
+//   * loads/stores are fully coalesced 16-/8-/4-byte per lane accesses,
+//   * compaction needs no global atomic at all: wave ballot + mbcnt prefix gives the slot inside the
+//     wave, one LDS add per wave orders the waves of the workgroup, and the stream length is a plain
+//     store at the end (a single global tail counter would saturate at ~90 M atomics/s on this chip),
+//   * K >> 256 CUs workgroups keep every XCD busy; a stream holds thousands of rays taken round-robin
+//     (256-ray chunks) from the whole pass, so all streams shrink at the same rate with depth.
+// Queue arrays (per ray): od0 = (ox,oy,oz,dx) 16 B, od1 = (dy,dz) 8 B, tp = (throughput rgb, pixel) 16 B,
+// meta 4 B; hit = (t, id) 8 B.  intersect moves 24+8 = 32 B/ray, shade 52 B in + 44 B out per survivor.
+#include "pt_kernels.h"
+
+namespace pt {
+
+__device__ __forceinline__ uint32_t lane_prefix(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+__device__ __forceinline__ void store_ray(const RayQueue &q, size_t at, vec3 o, vec3 d, vec3 thr, uint32_t pix,
+                                          uint32_t meta) {
+    q.od0[at] = make_float4(o.x, o.y, o.z, d.x);
+    q.od1[at] = make_float2(d.y, d.z);
+    q.tp[at] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(pix));
+    q.meta[at] = meta;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_generate(FrameParams F, RayQueue q, uint32_t *__restrict__ cnt0,
+                                                     uint32_t cap, uint32_t s0, uint64_t n_primary) {
+    const uint32_t b = blockIdx.x, K = gridDim.x, tid = threadIdx.x;
+    const size_t base = (size_t)b * cap;
+    uint32_t count = 0;
+    for (uint32_t j = 0;; ++j) {
+        const uint64_t first = ((uint64_t)j * K + b) * kBlock;  // 256-ray chunks dealt round-robin to streams
+        if (first >= n_primary) break;
+        const uint64_t g = first + tid;
+        if (g < n_primary) {
+            const uint32_t pl = (uint32_t)(g % F.npix);
+            const uint32_t s = s0 + (uint32_t)(g / F.npix);
+            const PathRay r = primary_ray(F, F.idx_begin + pl, s);
+            store_ray(q, base + (size_t)j * kBlock + tid, r.o, r.d, r.thr, r.pix, r.meta);
+        }
+        const uint64_t left = n_primary - first;
+        count += left < kBlock ? (uint32_t)left : kBlock;
+    }
+    if (tid == 0) cnt0[b] = count;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, RayQueue q, float2 *__restrict__ hit,
+                                                      const uint32_t *__restrict__ cnt, uint32_t cap,
+                                                      unsigned long long *__restrict__ blk_rays) {
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t n = cnt[b];
+    const size_t base = (size_t)b * cap;
+    for (uint32_t i = tid; i < n; i += kBlock) {
+        const float4 a = q.od0[base + i];
+        const float2 c = q.od1[base + i];
+        const HitRec h = intersect_scene_dev(S, mk(a.x, a.y, a.z), mk(a.w, c.x, c.y));
+        hit[base + i] = make_float2(h.t, __int_as_float(h.id));
+    }
+    if (tid == 0) blk_rays[b] += n;
+}
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void add_radiance(unsigned long long *__restrict__ acc, uint32_t npix, uint32_t pl,
+                                             vec3 v) {
+    const uint64_t r = to_fixed(v.x), g = to_fixed(v.y), bl = to_fixed(v.z);
+    if (r) atomicAdd(&acc[pl], (unsigned long long)r);
+    if (g) atomicAdd(&acc[(size_t)npix + pl], (unsigned long long)g);
+    if (bl) atomicAdd(&acc[2 * (size_t)npix + pl], (unsigned long long)bl);
+}
+
+__global__ __launch_bounds__(kBlock) void k_shade(DevScene S, FrameParams F, RayQueue qin, RayQueue qout,
+                                                  const float2 *__restrict__ hit,
+                                                  const uint32_t *__restrict__ cnt_in,
+                                                  uint32_t *__restrict__ cnt_out, uint32_t cap,
+                                                  unsigned long long *__restrict__ acc,
+                                                  uint32_t *__restrict__ flags) {
+    __shared__ uint32_t s_tail;
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) s_tail = 0;
+    __syncthreads();
+    const uint32_t n = cnt_in[b];
+    const size_t base = (size_t)b * cap;
+    bool overflow = false;
+    for (uint32_t j0 = 0; j0 < n; j0 += kBlock) {  // uniform trip count: every lane reaches the ballots
+        const uint32_t i = j0 + tid;
+        ShadeOut so;
+        so.n_rays = 0;
+        so.emits = false;
+        uint32_t pix = 0;
+        if (i < n) {
+            const float2 hr = hit[base + i];
+            HitRec h;
+            h.t = hr.x;
+            h.id = __float_as_int(hr.y);
+            if (h.id >= 0) {
+                const float4 a = qin.od0[base + i];
+                const float2 c = qin.od1[base + i];
+                const float4 tp = qin.tp[base + i];
+                PathRay in;
+                in.o = mk(a.x, a.y, a.z);
+                in.d = mk(a.w, c.x, c.y);
+                in.thr = mk(tp.x, tp.y, tp.z);
+                in.pix = __float_as_uint(tp.w);
+                in.meta = qin.meta[base + i];
+                pix = in.pix;
+                shade_hit(S, F, in, h, so);
+                if (so.emits) add_radiance(acc, F.npix, in.pix - F.idx_begin, so.contrib);
+            }
+        }
+        // stream compaction: survivors first (path order kept inside the wave), split children after them
+        const uint64_t m1 = __builtin_amdgcn_ballot_w64(so.n_rays >= 1);
+        const uint64_t m2 = __builtin_amdgcn_ballot_w64(so.n_rays == 2);
+        const uint32_t c1 = (uint32_t)__builtin_popcountll(m1), c2 = (uint32_t)__builtin_popcountll(m2);
+        uint32_t wbase = 0;
+        if ((tid & 63u) == 0u && (c1 + c2) != 0u) wbase = atomicAdd(&s_tail, c1 + c2);
+        wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+        if (so.n_rays >= 1) {
+            const uint32_t slot = wbase + lane_prefix(m1);
+            if (slot < cap)
+                store_ray(qout, base + slot, so.x, so.d0, so.thr0, pix, so.meta0);
+            else
+                overflow = true;
+        }
+        if (so.n_rays == 2) {
+            const uint32_t slot = wbase + c1 + lane_prefix(m2);
+            if (slot < cap)
+                store_ray(qout, base + slot, so.x, so.d1, so.thr1, pix, so.meta1);
+            else
+                overflow = true;
+        }
+    }
+    if (overflow) atomicOr(flags, 1u);
+    __syncthreads();
+    if (tid == 0) cnt_out[b] = s_tail < cap ? s_tail : cap;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_resolve(const unsigned long long *__restrict__ acc,
+                                                    float *__restrict__ out, uint32_t npix, uint32_t spp) {
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= npix) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double sum = (double)acc[(size_t)c * npix + p] * (1.0 / 4294967296.0);
+        const float v = (float)sum / (float)spp;  // radiance_v / samples_per_pixel, mod.rs:849
+        out[(size_t)p * 3 + c] = clamp01(v);      // mod.rs:852-856
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent megakernel: one lane = one (pixel, sample chunk); the lane walks its samples one after the
+// other and each loop trip advances every live path of the wave by one bounce, so the intersect and
+// shade code is executed by (nearly) full waves whatever the depths of the individual paths.
+// The refract split (mod.rs:775-786) pushes the transmitted ray on a two-entry stack in registers.
+__global__ __launch_bounds__(kBlock) void k_mega(DevScene S, FrameParams F, unsigned long long *__restrict__ acc,
+                                                 uint32_t chunk_spp, uint32_t n_chunks,
+                                                 unsigned long long *__restrict__ total_rays) {
+    const uint64_t items = (uint64_t)F.npix * n_chunks;
+    unsigned long long rays = 0;
+    for (uint64_t first = (uint64_t)blockIdx.x * kBlock; first < items; first += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t item = first + threadIdx.x;
+        const bool lane_valid = item < items;
+        const uint32_t pl = lane_valid ? (uint32_t)(item % F.npix) : 0u;
+        const uint32_t chunk = lane_valid ? (uint32_t)(item / F.npix) : 0u;
+        uint32_t s = chunk * chunk_spp;
+        const uint32_t s_lim = s + chunk_spp;
+        const uint32_t s_end = lane_valid ? (s_lim < F.spp ? s_lim : F.spp) : s;
+        uint64_t ar = 0, ag = 0, ab = 0;
+        PathRay cur, st0, st1;
+        cur.o = cur.d = cur.thr = mk(0.0f, 0.0f, 0.0f);
+        cur.pix = 0;
+        cur.meta = 0;
+        st0 = cur;
+        st1 = cur;
+        int sp = 0;
+        bool active = false;
+        for (;;) {
+            if (!active) {
+                if (sp == 2) {
+                    cur = st1;
+                    sp = 1;
+                    active = true;
+                } else if (sp == 1) {
+                    cur = st0;
+                    sp = 0;
+                    active = true;
+                } else if (s < s_end) {
+                    cur = primary_ray(F, F.idx_begin + pl, s);
+                    ++s;
+                    active = true;
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+            if (active) {
+                const HitRec h = intersect_scene_dev(S, cur.o, cur.d);
+                ++rays;
+                if (h.id < 0) {
+                    active = false;
+                } else {
+                    ShadeOut so;
+                    shade_hit(S, F, cur, h, so);
+                    if (so.emits) {
+                        ar += to_fixed(so.contrib.x);
+                        ag += to_fixed(so.contrib.y);
+                        ab += to_fixed(so.contrib.z);
+                    }
+                    if (so.n_rays == 0) {
+                        active = false;
+                    } else {
+                        cur.o = so.x;
+                        cur.d = so.d0;
+                        cur.thr = so.thr0;
+                        cur.meta = so.meta0;
+                        if (so.n_rays == 2) {
+                            PathRay child = cur;
+                            child.d = so.d1;
+                            child.thr = so.thr1;
+                            child.meta = so.meta1;
+                            if (sp == 0)
+                                st0 = child;
+                            else
+                                st1 = child;
+                            ++sp;
+                        }
+                    }
+                }
+            }
+        }
+        if (lane_valid) {
+            if (ar) atomicAdd(&acc[pl], (unsigned long long)ar);
+            if (ag) atomicAdd(&acc[(size_t)F.npix + pl], (unsigned long long)ag);
+            if (ab) atomicAdd(&acc[2 * (size_t)F.npix + pl], (unsigned long long)ab);
+        }
+    }
+    // one counter update per wave
+    for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
+    if ((threadIdx.x & 63u) == 0u && rays) atomicAdd(total_rays, rays);
+}
+
+// ------------------------------------------------------------------------------------------------
+// single-ray queries (picking / click-debug callers of intersect_scene)
+__global__ __launch_bounds__(kBlock) void k_query(DevScene S, const float *__restrict__ o,
+                                                  const float *__restrict__ d, uint32_t n, float *__restrict__ t,
+                                                  int32_t *__restrict__ object_id, int32_t *__restrict__ tri_id,
+                                                  float *__restrict__ x, float *__restrict__ nrm) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const vec3 ro = mk(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
+        const vec3 rd = mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+        const HitRec h = intersect_scene_dev(S, ro, rd);
+        int32_t oid = -1, tid = -1;
+        vec3 hx = mk(0.0f, 0.0f, 0.0f), hn = hx;
+        float ht = 0.0f;
+        if (h.id >= 0) {
+            const Surface sf = fetch_surface(S, ro, rd, h);
+            hx = sf.x;
+            hn = sf.n;
+            ht = h.t;
+            if (h.id >= (int32_t)S.n_objs) {
+                const uint32_t k = (uint32_t)(h.id - (int32_t)S.n_objs);
+                oid = (int32_t)S.tri_shade[k].owner;
+                tid = (int32_t)(k - S.objs[oid].tri_begin);
+            } else {
+                oid = h.id;
+            }
+        }
+        t[i] = ht;
+        object_id[i] = oid;
+        tri_id[i] = tid;
+        x[3 * i] = hx.x;
+        x[3 * i + 1] = hx.y;
+        x[3 * i + 2] = hx.z;
+        nrm[3 * i] = hn.x;
+        nrm[3 * i + 1] = hn.y;
+        nrm[3 * i + 2] = hn.z;
+    }
+}
+
+// numerics self-check kernel: the device evaluates the contract functions on given inputs so that the
+// tests can compare them bit for bit with the oracle's host evaluation.
+__global__ void k_numerics(const float *__restrict__ in, uint32_t n, float *__restrict__ out_sin,
+                           float *__restrict__ out_cos, float *__restrict__ out_sqrt, float *__restrict__ out_rcp,
+                           uint32_t *__restrict__ out_philox) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = in[i];
+    float s, c;
+    sincos_f32(v, &s, &c);
+    out_sin[i] = s;
+    out_cos[i] = c;
+    out_sqrt[i] = f_sqrt(v);
+    out_rcp[i] = 1.0f / v;
+    const u32x4 r = draw_block(0x0123456789abcdefull, i, __float_as_uint(v), (i << 8) | (i & 15u));
+    out_philox[4 * i + 0] = r.a;
+    out_philox[4 * i + 1] = r.b;
+    out_philox[4 * i + 2] = r.c;
+    out_philox[4 * i + 3] = r.d;
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+void launch_generate(hipStream_t st, uint32_t K, const FrameParams &F, const RayQueue &q, uint32_t *cnt0,
+                     uint32_t cap, uint32_t s0, uint64_t n_primary) {
+    hipLaunchKernelGGL(k_generate, dim3(K), dim3(kBlock), 0, st, F, q, cnt0, cap, s0, n_primary);
+}
+void launch_intersect(hipStream_t st, uint32_t K, const DevScene &S, const RayQueue &q, float2 *hit,
+                      const uint32_t *cnt, uint32_t cap, unsigned long long *blk_rays) {
+    hipLaunchKernelGGL(k_intersect, dim3(K), dim3(kBlock), 0, st, S, q, hit, cnt, cap, blk_rays);
+}
+void launch_shade(hipStream_t st, uint32_t K, const DevScene &S, const FrameParams &F, const RayQueue &qin,
+                  const RayQueue &qout, const float2 *hit, const uint32_t *cnt_in, uint32_t *cnt_out, uint32_t cap,
+                  unsigned long long *acc, uint32_t *flags) {
+    hipLaunchKernelGGL(k_shade, dim3(K), dim3(kBlock), 0, st, S, F, qin, qout, hit, cnt_in, cnt_out, cap, acc,
+                       flags);
+}
+void launch_resolve(hipStream_t st, const unsigned long long *acc, float *out, uint32_t npix, uint32_t spp) {
+    hipLaunchKernelGGL(k_resolve, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, st, acc, out, npix, spp);
+}
+void launch_mega(hipStream_t st, uint32_t grid, const DevScene &S, const FrameParams &F, unsigned long long *acc,
+                 uint32_t chunk_spp, uint32_t n_chunks, unsigned long long *total_rays) {
+    hipLaunchKernelGGL(k_mega, dim3(grid), dim3(kBlock), 0, st, S, F, acc, chunk_spp, n_chunks, total_rays);
+}
+void launch_query(hipStream_t st, const DevScene &S, const float *o, const float *d, uint32_t n, float *t,
+                  int32_t *object_id, int32_t *tri_id, float *x, float *nrm) {
+    uint32_t grid = (n + kBlock - 1) / kBlock;
+    if (grid > 4096u) grid = 4096u;
+    if (grid == 0u) grid = 1u;
+    hipLaunchKernelGGL(k_query, dim3(grid), dim3(kBlock), 0, st, S, o, d, n, t, object_id, tri_id, x, nrm);
+}
+void launch_numerics(hipStream_t st, const float *in, uint32_t n, float *out_sin, float *out_cos, float *out_sqrt,
+                     float *out_rcp, uint32_t *out_philox) {
+    hipLaunchKernelGGL(k_numerics, dim3((n + 255u) / 256u), dim3(256), 0, st, in, n, out_sin, out_cos, out_sqrt,
+                       out_rcp, out_philox);
+}
+
+}  // namespace pt

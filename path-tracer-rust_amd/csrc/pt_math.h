@@ -1,0 +1,175 @@
+// pt_math.h — numerics contract of the MI355X radiance() path, shared by host and device code.
+//
+// Every function here is a strict per-operation IEEE-754 binary32 (or binary64 inside sin/cos)
+// evaluation in the order the reference evaluates it; the translation units that include this
+// header are built with -ffp-contract=off -fno-fast-math so neither hipcc nor the host compiler
+// fuses or reassociates anything (rustc/LLVM never does for the reference either).
+//
+// Reference semantics restated (citations relative to /root/reference):
+//   glam 0.30.8 scalar Vec3 (Cargo.lock:1508)  dot, cross, length, normalize = v*(1/len)
+//   rand 0.8.5 Standard<f32> (mod.rs:53)       (u32 >> 8) * 2^-24
+//   f32::sin / f32::cos (mod.rs:703)            libm sinf/cosf; glibc's double-polynomial algorithm,
+//                                              bit-identical to glibc 2.35 on all 2^24 reachable
+//                                              arguments (tests/test_oracle.py)
+//   powi(2), powi(5) (mod.rs:416,741,754)      x*x, x*((x*x)*(x*x))
+// rand01() itself (ThreadRng, OS seeded) is replaced by Philox4x32-10 keyed per
+// (seed, pixel, sample, branch, depth) so that CPU and GPU draw the same numbers in any order.
+#pragma once
+
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define PT_HD __host__ __device__ __forceinline__
+#else
+#include <math.h>
+#define PT_HD static inline
+#endif
+
+namespace pt {
+
+struct vec3 {
+    float x, y, z;
+};
+
+PT_HD vec3 mk(float x, float y, float z) {
+    vec3 r;
+    r.x = x;
+    r.y = y;
+    r.z = z;
+    return r;
+}
+PT_HD vec3 operator+(vec3 a, vec3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+PT_HD vec3 operator-(vec3 a, vec3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+PT_HD vec3 operator*(vec3 a, vec3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+PT_HD vec3 operator*(vec3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+PT_HD vec3 operator/(vec3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+PT_HD float dot(vec3 a, vec3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+PT_HD vec3 cross(vec3 a, vec3 b) {
+    return mk(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
+}
+// IEEE correctly rounded on both sides: x86 sqrtss, and llvm.sqrt.f32 under
+// -fhip-fp32-correctly-rounded-divide-sqrt (HIP's __fsqrt_rn is the 1-ulp native v_sqrt_f32: not usable)
+PT_HD float f_sqrt(float x) { return __builtin_sqrtf(x); }
+PT_HD float f_abs(float x) { return __builtin_fabsf(x); }
+PT_HD float f_max(float a, float b) { return __builtin_fmaxf(a, b); }
+PT_HD float length(vec3 a) { return f_sqrt(dot(a, a)); }
+PT_HD vec3 normalize(vec3 a) { return a * (1.0f / length(a)); }
+
+// ---- rand 0.8.5: 24 high bits of a u32 -> [0,1)
+PT_HD float unit_f32(uint32_t u) { return (float)(u >> 8) * (1.0f / 16777216.0f); }
+
+// ---- Philox4x32-10 (Salmon et al., SC'11); KATs in tests/test_oracle.py
+struct u32x4 {
+    uint32_t a, b, c, d;
+};
+
+PT_HD uint32_t mulhi32(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32);
+#endif
+}
+
+PT_HD u32x4 philox4x32_10(u32x4 ctr, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int round = 0; round < 10; ++round) {
+        const uint32_t hi0 = mulhi32(0xD2511F53u, ctr.a), lo0 = 0xD2511F53u * ctr.a;
+        const uint32_t hi1 = mulhi32(0xCD9E8D57u, ctr.c), lo1 = 0xCD9E8D57u * ctr.c;
+        u32x4 nx;
+        nx.a = hi1 ^ ctr.b ^ k0;
+        nx.b = lo1;
+        nx.c = hi0 ^ ctr.d ^ k1;
+        nx.d = lo0;
+        ctr = nx;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return ctr;
+}
+
+// RNG contract: counter = (pixel index in the frame, sample index, tag, 0), key = seed.
+//   tag 0                      : camera draws of a sample (a -> r1, b -> r2; mod.rs:818-819)
+//   tag (branch<<8)|new_depth  : one radiance() invocation (a -> roulette mod.rs:678,
+//                                b -> diffuse r1 / refract choice mod.rs:691,761, c -> diffuse r2 mod.rs:692)
+PT_HD u32x4 draw_block(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t tag) {
+    u32x4 c;
+    c.a = pixel;
+    c.b = sample;
+    c.c = tag;
+    c.d = 0u;
+    return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+// ---- sinf / cosf for |y| < 120: glibc (ARM optimized-routines) algorithm, evaluated in binary64
+namespace sc {
+constexpr double kHpiInv = 0x1.45F306DC9C883p+23;  // 2/pi * 2^24
+constexpr double kHpi = 0x1.921FB54442D18p0;
+constexpr double kC0 = 0x1p0, kC1 = -0x1.ffffffd0c621cp-2, kC2 = 0x1.55553e1068f19p-5,
+                 kC3 = -0x1.6c087e89a359dp-10, kC4 = 0x1.99343027bf8c3p-16;
+constexpr double kS1 = -0x1.555545995a603p-3, kS2 = 0x1.1107605230bc4p-7, kS3 = -0x1.994eb3774cf24p-13;
+
+PT_HD uint32_t top12(float f) {
+    uint32_t u;
+    memcpy(&u, &f, sizeof u);
+    return (u >> 20) & 0x7ffu;
+}
+PT_HD float sin_poly(double x, double x2) {
+    const double x3 = x * x2;
+    const double s1 = kS2 + x2 * kS3;
+    const double x7 = x3 * x2;
+    const double s = x + x3 * kS1;
+    return (float)(s + x7 * s1);
+}
+// `flip` selects the negated cosine table (quadrants 2 and 3)
+PT_HD float cos_poly(double x2, bool flip) {
+    const double g = flip ? -1.0 : 1.0;
+    const double x4 = x2 * x2;
+    const double c2 = g * kC3 + x2 * (g * kC4);
+    const double c1 = g * kC1 + x2 * (g * kC2);
+    const double x6 = x4 * x2;
+    const double c = g * kC0 + x2 * c1;
+    return (float)(c + x6 * c2);
+}
+}  // namespace sc
+
+// sine and cosine of one argument share the range reduction (same results as two separate calls)
+PT_HD void sincos_f32(float y, float *s_out, float *c_out) {
+    double x = (double)y;
+    if (sc::top12(y) < sc::top12(0x1.921FB6p-1f)) {
+        if (sc::top12(y) < sc::top12(0x1p-12f)) {
+            *s_out = y;
+            *c_out = 1.0f;
+            return;
+        }
+        const double x2 = x * x;
+        *s_out = sc::sin_poly(x, x2);
+        *c_out = sc::cos_poly(x2, false);
+        return;
+    }
+    const double r = x * sc::kHpiInv;
+    const int n = ((int32_t)r + 0x800000) >> 24;
+    x = x - (double)n * sc::kHpi;
+    const int q = n & 3;
+    const double sgn = (q == 1 || q == 2) ? -1.0 : 1.0;
+    const double xs = x * sgn;
+    const double x2 = x * x;
+    const bool flip = (n & 2) != 0;
+    // sinf uses polynomial index n, cosf uses n^1: even -> sine polynomial, odd -> cosine polynomial
+    if ((n & 1) == 0) {
+        *s_out = sc::sin_poly(xs, x2);
+        *c_out = sc::cos_poly(x2, flip);
+    } else {
+        *s_out = sc::cos_poly(x2, flip);
+        *c_out = sc::sin_poly(xs, x2);
+    }
+}
+
+// tent filter of render_pixel (mod.rs:820-830)
+PT_HD float tent(float r) { return r < 1.0f ? f_sqrt(r) - 1.0f : 1.0f - f_sqrt(2.0f - r); }
+
+PT_HD float clamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
+
+}  // namespace pt

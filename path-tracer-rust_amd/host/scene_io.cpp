@@ -1,0 +1,595 @@
+// scene_io.cpp — the on-disk formats either side of the hot path, host only.
+//
+//   pt_scene_load   SceneDescriptor::load + to_data      src/render/mod.rs:92-110, 304-318
+//                   (serde_json, externally tagged enums; JSON number -> f64 -> `as f32`)
+//   pt_load_off     load_off                              src/render/load_off.rs:8-85
+//   pt_write_ppm    the P3 writer of render()             src/render/mod.rs:1043-1076
+//   pt_gamma_*      gamma_correction / to_int_with_...    src/render/mod.rs:57-63
+//
+// Where the reference panics (unwrap) this code returns PT_ERR_PARSE / PT_ERR_IO with a message.
+#include <cerrno>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/ptrace.h"
+#include "../csrc/pt_host.h"
+
+namespace {
+
+// ------------------------------------------------------------------ minimal JSON value + parser
+struct JValue;
+using JPtr = std::unique_ptr<JValue>;
+struct JValue {
+    enum Kind { Null, Bool, Num, Str, Arr, Obj } kind = Null;
+    bool b = false;
+    double num = 0.0;
+    std::string str;
+    std::vector<JPtr> arr;
+    std::vector<std::pair<std::string, JPtr>> obj;  // insertion order; serde takes the last duplicate? (first here)
+    const JValue *get(const char *key) const {
+        if (kind != Obj) return nullptr;
+        for (const auto &kv : obj)
+            if (kv.first == key) return kv.second.get();
+        return nullptr;
+    }
+};
+
+struct JParser {
+    const char *p, *end;
+    std::string err;
+    explicit JParser(const std::string &s) : p(s.data()), end(s.data() + s.size()) {}
+    void ws() {
+        while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p;
+    }
+    bool fail(const std::string &m) {
+        if (err.empty()) err = m;
+        return false;
+    }
+    bool lit(const char *s) {
+        size_t n = strlen(s);
+        if ((size_t)(end - p) >= n && memcmp(p, s, n) == 0) {
+            p += n;
+            return true;
+        }
+        return false;
+    }
+    bool parse_string(std::string &out) {
+        if (p >= end || *p != '"') return fail("expected string");
+        ++p;
+        out.clear();
+        while (p < end && *p != '"') {
+            if (*p == '\\') {
+                ++p;
+                if (p >= end) return fail("bad escape");
+                switch (*p) {
+                    case '"': out += '"'; break;
+                    case '\\': out += '\\'; break;
+                    case '/': out += '/'; break;
+                    case 'b': out += '\b'; break;
+                    case 'f': out += '\f'; break;
+                    case 'n': out += '\n'; break;
+                    case 'r': out += '\r'; break;
+                    case 't': out += '\t'; break;
+                    case 'u': {
+                        if (end - p < 5) return fail("bad \\u escape");
+                        unsigned cp = 0;
+                        for (int i = 1; i <= 4; ++i) {
+                            char c = p[i];
+                            cp <<= 4;
+                            if (c >= '0' && c <= '9') cp |= (unsigned)(c - '0');
+                            else if (c >= 'a' && c <= 'f') cp |= (unsigned)(c - 'a' + 10);
+                            else if (c >= 'A' && c <= 'F') cp |= (unsigned)(c - 'A' + 10);
+                            else return fail("bad \\u escape");
+                        }
+                        p += 4;
+                        if (cp < 0x80) out += (char)cp;
+                        else if (cp < 0x800) {
+                            out += (char)(0xC0 | (cp >> 6));
+                            out += (char)(0x80 | (cp & 0x3F));
+                        } else {
+                            out += (char)(0xE0 | (cp >> 12));
+                            out += (char)(0x80 | ((cp >> 6) & 0x3F));
+                            out += (char)(0x80 | (cp & 0x3F));
+                        }
+                        break;
+                    }
+                    default: return fail("bad escape");
+                }
+                ++p;
+            } else {
+                out += *p++;
+            }
+        }
+        if (p >= end) return fail("unterminated string");
+        ++p;
+        return true;
+    }
+    bool parse_value(JValue &v, int depth) {
+        if (depth > 64) return fail("nesting too deep");
+        ws();
+        if (p >= end) return fail("unexpected end of input");
+        if (*p == '{') {
+            ++p;
+            v.kind = JValue::Obj;
+            ws();
+            if (p < end && *p == '}') {
+                ++p;
+                return true;
+            }
+            for (;;) {
+                ws();
+                std::string key;
+                if (!parse_string(key)) return false;
+                ws();
+                if (p >= end || *p != ':') return fail("expected ':'");
+                ++p;
+                JPtr child(new JValue());
+                if (!parse_value(*child, depth + 1)) return false;
+                v.obj.emplace_back(std::move(key), std::move(child));
+                ws();
+                if (p < end && *p == ',') {
+                    ++p;
+                    continue;
+                }
+                if (p < end && *p == '}') {
+                    ++p;
+                    return true;
+                }
+                return fail("expected ',' or '}'");
+            }
+        }
+        if (*p == '[') {
+            ++p;
+            v.kind = JValue::Arr;
+            ws();
+            if (p < end && *p == ']') {
+                ++p;
+                return true;
+            }
+            for (;;) {
+                JPtr child(new JValue());
+                if (!parse_value(*child, depth + 1)) return false;
+                v.arr.push_back(std::move(child));
+                ws();
+                if (p < end && *p == ',') {
+                    ++p;
+                    continue;
+                }
+                if (p < end && *p == ']') {
+                    ++p;
+                    return true;
+                }
+                return fail("expected ',' or ']'");
+            }
+        }
+        if (*p == '"') {
+            v.kind = JValue::Str;
+            return parse_string(v.str);
+        }
+        if (lit("true")) {
+            v.kind = JValue::Bool;
+            v.b = true;
+            return true;
+        }
+        if (lit("false")) {
+            v.kind = JValue::Bool;
+            v.b = false;
+            return true;
+        }
+        if (lit("null")) {
+            v.kind = JValue::Null;
+            return true;
+        }
+        // number: JSON grammar, value through strtod (serde_json: decimal -> f64)
+        const char *s = p;
+        if (p < end && *p == '-') ++p;
+        if (p >= end || !(*p >= '0' && *p <= '9')) return fail("unexpected character");
+        while (p < end && *p >= '0' && *p <= '9') ++p;
+        if (p < end && *p == '.') {
+            ++p;
+            if (p >= end || !(*p >= '0' && *p <= '9')) return fail("bad number");
+            while (p < end && *p >= '0' && *p <= '9') ++p;
+        }
+        if (p < end && (*p == 'e' || *p == 'E')) {
+            ++p;
+            if (p < end && (*p == '+' || *p == '-')) ++p;
+            if (p >= end || !(*p >= '0' && *p <= '9')) return fail("bad exponent");
+            while (p < end && *p >= '0' && *p <= '9') ++p;
+        }
+        std::string tok(s, p);
+        v.kind = JValue::Num;
+        v.num = strtod(tok.c_str(), nullptr);
+        return true;
+    }
+};
+
+struct Ctx {
+    std::string err;
+    bool fail(const std::string &m) {
+        if (err.empty()) err = m;
+        return false;
+    }
+};
+
+bool get_f32(Ctx &c, const JValue *v, const char *what, float *out) {
+    if (!v || v->kind != JValue::Num) return c.fail(std::string("missing or non-numeric field `") + what + "`");
+    *out = (float)v->num;  // f64 -> f32, as serde's f32 visitor does
+    return true;
+}
+
+bool get_vec3(Ctx &c, const JValue *v, const char *what, float out[3]) {
+    if (!v || v->kind != JValue::Arr || v->arr.size() != 3)
+        return c.fail(std::string("field `") + what + "` must be an array of 3 numbers");
+    for (int i = 0; i < 3; ++i)
+        if (!get_f32(c, v->arr[i].get(), what, &out[i])) return false;
+    return true;
+}
+
+std::string trim(const std::string &s) {
+    size_t a = 0, b = s.size();
+    while (a < b && isspace((unsigned char)s[a])) ++a;
+    while (b > a && isspace((unsigned char)s[b - 1])) --b;
+    return s.substr(a, b - a);
+}
+
+std::vector<std::string> split_ws(const std::string &s) {
+    std::vector<std::string> out;
+    size_t i = 0;
+    while (i < s.size()) {
+        while (i < s.size() && isspace((unsigned char)s[i])) ++i;
+        size_t j = i;
+        while (j < s.size() && !isspace((unsigned char)s[j])) ++j;
+        if (j > i) out.push_back(s.substr(i, j - i));
+        i = j;
+    }
+    return out;
+}
+
+// Rust str::parse::<usize>(): optional '+', decimal digits only
+bool parse_usize(const std::string &t, uint64_t *out) {
+    size_t i = 0;
+    if (i < t.size() && t[i] == '+') ++i;
+    if (i >= t.size()) return false;
+    uint64_t v = 0;
+    for (; i < t.size(); ++i) {
+        if (t[i] < '0' || t[i] > '9') return false;
+        if (v > (UINT64_MAX - 9) / 10) return false;
+        v = v * 10 + (uint64_t)(t[i] - '0');
+    }
+    *out = v;
+    return true;
+}
+
+// Rust str::parse::<f32>(): correctly rounded decimal -> f32 (strtof), no hex, whole token
+bool parse_f32(const std::string &t, float *out) {
+    if (t.empty()) return false;
+    for (char ch : t)
+        if (ch == 'x' || ch == 'X' || ch == 'p' || ch == 'P') return false;
+    char *e = nullptr;
+    errno = 0;
+    float v = strtof(t.c_str(), &e);
+    if (e != t.c_str() + t.size()) return false;
+    *out = v;
+    return true;
+}
+
+int load_off_impl(const std::string &path, float scale, std::vector<pt_triangle> &out, std::string &err) {
+    std::ifstream f(path);
+    if (!f) {
+        err = "cannot open " + path;
+        return PT_ERR_IO;
+    }
+    bool eof = false;
+    auto get_line = [&](std::string &line) -> bool {  // skips blank and '#' lines (load_off.rs:12-20)
+        for (;;) {
+            std::string raw;
+            if (!std::getline(f, raw)) {
+                eof = true;
+                return false;
+            }
+            line = trim(raw);
+            if (!line.empty() && line[0] != '#') return true;
+        }
+    };
+    std::string line;
+    if (!get_line(line) || line != "OFF") {
+        err = eof ? "unexpected end of file" : "Invalid header";
+        return PT_ERR_PARSE;
+    }
+    if (!get_line(line)) {
+        err = "unexpected end of file";
+        return PT_ERR_PARSE;
+    }
+    std::vector<std::string> tk = split_ws(line);
+    uint64_t nv = 0, nf = 0, ne = 0;
+    if (tk.size() != 3 || !parse_usize(tk[0], &nv) || !parse_usize(tk[1], &nf) || !parse_usize(tk[2], &ne)) {
+        err = "Invalid element counts";
+        return PT_ERR_PARSE;
+    }
+    if (nv > (1u << 28) || nf > (1u << 28)) {
+        err = "mesh too large";
+        return PT_ERR_PARSE;
+    }
+    std::vector<pt::vec3> verts;
+    verts.reserve((size_t)nv);
+    for (uint64_t i = 0; i < nv; ++i) {
+        if (!get_line(line)) {
+            err = "unexpected end of file";
+            return PT_ERR_PARSE;
+        }
+        tk = split_ws(line);
+        float c[3];
+        if (tk.size() != 3 || !parse_f32(tk[0], &c[0]) || !parse_f32(tk[1], &c[1]) || !parse_f32(tk[2], &c[2])) {
+            err = "Invalid vertex coordinates";
+            return PT_ERR_PARSE;
+        }
+        verts.push_back(pt::mk(c[0], c[1], c[2]) * scale);  // Vec3::new(..) * scale, load_off.rs:52
+    }
+    out.clear();
+    out.reserve((size_t)nf);
+    for (uint64_t i = 0; i < nf; ++i) {
+        if (!get_line(line)) {
+            err = "unexpected end of file";
+            return PT_ERR_PARSE;
+        }
+        tk = split_ws(line);
+        uint64_t idx[4];
+        if (tk.size() < 4 || !parse_usize(tk[0], &idx[0]) || !parse_usize(tk[1], &idx[1]) ||
+            !parse_usize(tk[2], &idx[2]) || !parse_usize(tk[3], &idx[3]) || idx[0] != 3) {
+            err = "Invalid face: " + line;  // only triangles are supported (load_off.rs:73-76)
+            return PT_ERR_PARSE;
+        }
+        if (idx[1] >= nv || idx[2] >= nv || idx[3] >= nv) {
+            err = "face index out of range: " + line;
+            return PT_ERR_PARSE;
+        }
+        pt_triangle t;
+        const pt::vec3 a = verts[idx[1]], b = verts[idx[2]], c = verts[idx[3]];
+        t.a[0] = a.x, t.a[1] = a.y, t.a[2] = a.z;
+        t.b[0] = b.x, t.b[1] = b.y, t.b[2] = b.z;
+        t.c[0] = c.x, t.c[1] = c.y, t.c[2] = c.z;
+        out.push_back(t);
+    }
+    return PT_OK;
+}
+
+}  // namespace
+
+struct pt_scene {
+    std::string id;
+    pt_camera camera{};
+    std::vector<pt_object> objects;
+    std::vector<pt_triangle> triangles;
+};
+
+extern "C" {
+
+int pt_load_off(const char *path, float scale, pt_triangle **tris, uint32_t *n_tris) {
+    if (!path || !tris || !n_tris) {
+        pt::set_error("NULL argument");
+        return PT_ERR_INVALID;
+    }
+    std::vector<pt_triangle> v;
+    std::string err;
+    int rc = load_off_impl(path, scale, v, err);
+    if (rc) {
+        pt::set_error(err);
+        return rc;
+    }
+    *n_tris = (uint32_t)v.size();
+    *tris = (pt_triangle *)malloc(sizeof(pt_triangle) * (v.empty() ? 1 : v.size()));
+    if (!*tris) {
+        pt::set_error("out of memory");
+        return PT_ERR_INVALID;
+    }
+    if (!v.empty()) memcpy(*tris, v.data(), sizeof(pt_triangle) * v.size());
+    return PT_OK;
+}
+
+void pt_free(void *p) { free(p); }
+
+int pt_scene_load(const char *path, const char *base_dir, pt_scene **out) {
+    if (!path || !out) {
+        pt::set_error("NULL argument");
+        return PT_ERR_INVALID;
+    }
+    *out = nullptr;
+    std::ifstream f(path, std::ios::binary);
+    if (!f) {
+        pt::set_error(std::string("cannot open ") + path);
+        return PT_ERR_IO;
+    }
+    std::stringstream ss;
+    ss << f.rdbuf();
+    const std::string text = ss.str();
+    JParser jp(text);
+    JValue root;
+    if (!jp.parse_value(root, 0)) {
+        pt::set_error("JSON: " + jp.err);
+        return PT_ERR_PARSE;
+    }
+    jp.ws();
+    if (jp.p != jp.end) {
+        pt::set_error("JSON: trailing characters");
+        return PT_ERR_PARSE;
+    }
+    Ctx c;
+    std::unique_ptr<pt_scene> sc(new pt_scene());
+    const JValue *jid = root.get("id");
+    const JValue *jobjs = root.get("objects");
+    const JValue *jcam = root.get("camera");
+    if (!jid || jid->kind != JValue::Str || !jobjs || jobjs->kind != JValue::Arr || !jcam || jcam->kind != JValue::Obj) {
+        pt::set_error("scene: missing `id`, `objects` or `camera`");
+        return PT_ERR_PARSE;
+    }
+    sc->id = jid->str;
+    if (!get_vec3(c, jcam->get("position"), "camera.position", sc->camera.position) ||
+        !get_vec3(c, jcam->get("direction"), "camera.direction", sc->camera.direction) ||
+        !get_f32(c, jcam->get("focal_length"), "camera.focal_length", &sc->camera.focal_length) ||
+        !get_f32(c, jcam->get("sensor_width"), "camera.sensor_width", &sc->camera.sensor_width) ||
+        !get_f32(c, jcam->get("aspect_ratio"), "camera.aspect_ratio", &sc->camera.aspect_ratio)) {
+        pt::set_error("scene: " + c.err);
+        return PT_ERR_PARSE;
+    }
+    const std::string base = base_dir ? base_dir : ".";
+    for (size_t i = 0; i < jobjs->arr.size(); ++i) {
+        const JValue &jo = *jobjs->arr[i];
+        const std::string where = "objects[" + std::to_string(i) + "]";
+        pt_object o;
+        memset(&o, 0, sizeof o);
+        const JValue *jt = jo.get("type_"), *jm = jo.get("material");
+        if (jo.kind != JValue::Obj || !jt || !jm || jm->kind != JValue::Obj ||
+            !get_vec3(c, jo.get("position"), "position", o.position) ||
+            !get_vec3(c, jm->get("color"), "material.color", o.color) ||
+            !get_vec3(c, jm->get("emmission"), "material.emmission", o.emission)) {
+            pt::set_error("scene: " + where + ": " + (c.err.empty() ? "missing `type_` or `material`" : c.err));
+            return PT_ERR_PARSE;
+        }
+        const JValue *jr = jm->get("reflect_type");
+        if (!jr || jr->kind != JValue::Str) {
+            pt::set_error("scene: " + where + ": missing material.reflect_type");
+            return PT_ERR_PARSE;
+        }
+        if (jr->str == "Diffuse") o.reflect_type = PT_DIFFUSE;
+        else if (jr->str == "Specular") o.reflect_type = PT_SPECULAR;
+        else if (jr->str == "Refract") o.reflect_type = PT_REFRACT;
+        else {
+            pt::set_error("scene: " + where + ": unknown reflect_type `" + jr->str + "`");
+            return PT_ERR_PARSE;
+        }
+        // externally tagged enum: {"Sphere":{..}} | {"MeshFile":{..}} | {"Mesh":{..}}
+        if (jt->kind != JValue::Obj || jt->obj.size() != 1 || jt->obj[0].second->kind != JValue::Obj) {
+            pt::set_error("scene: " + where + ": `type_` must be a single-key object");
+            return PT_ERR_PARSE;
+        }
+        const std::string &tag = jt->obj[0].first;
+        const JValue &body = *jt->obj[0].second;
+        if (tag == "Sphere") {
+            o.kind = PT_SPHERE;
+            if (!get_f32(c, body.get("radius"), "Sphere.radius", &o.radius)) {
+                pt::set_error("scene: " + where + ": " + c.err);
+                return PT_ERR_PARSE;
+            }
+        } else if (tag == "MeshFile") {
+            o.kind = PT_MESH;
+            const JValue *jp_ = body.get("path");
+            float scale = 0.0f;
+            if (!jp_ || jp_->kind != JValue::Str || !get_f32(c, body.get("scale"), "MeshFile.scale", &scale)) {
+                pt::set_error("scene: " + where + ": MeshFile needs `path` and `scale`");
+                return PT_ERR_PARSE;
+            }
+            std::vector<pt_triangle> tl;
+            std::string err;
+            const std::string full = (jp_->str.size() && jp_->str[0] == '/') ? jp_->str : base + "/" + jp_->str;
+            int rc = load_off_impl(full, scale, tl, err);
+            if (rc) {
+                pt::set_error("scene: " + where + ": " + err);
+                return rc;
+            }
+            if (tl.empty()) {
+                pt::set_error("scene: " + where + ": mesh file has no triangles");
+                return PT_ERR_PARSE;
+            }
+            o.tri_offset = (uint32_t)sc->triangles.size();
+            o.tri_count = (uint32_t)tl.size();
+            pt::host::mesh_bounding_sphere(tl.data(), (uint32_t)tl.size(), o.bs_center, &o.bs_radius);  // Mesh::new
+            sc->triangles.insert(sc->triangles.end(), tl.begin(), tl.end());
+        } else if (tag == "Mesh") {
+            o.kind = PT_MESH;
+            const JValue *jtri = body.get("triangles"), *jbs = body.get("bounding_sphere");
+            // `bounding_box` must be present for serde to accept the Mesh, but the tracer never reads it
+            const JValue *jbb = body.get("bounding_box");
+            if (!jtri || jtri->kind != JValue::Arr || !jbs || jbs->kind != JValue::Obj || !jbb || jbb->kind != JValue::Arr ||
+                !get_vec3(c, jbs->get("position"), "bounding_sphere.position", o.bs_center) ||
+                !get_f32(c, jbs->get("radius"), "bounding_sphere.radius", &o.bs_radius)) {
+                pt::set_error("scene: " + where + ": Mesh needs `triangles`, `bounding_sphere`, `bounding_box`" +
+                              (c.err.empty() ? "" : " (" + c.err + ")"));
+                return PT_ERR_PARSE;
+            }
+            o.tri_offset = (uint32_t)sc->triangles.size();
+            o.tri_count = (uint32_t)jtri->arr.size();
+            for (const auto &jtv : jtri->arr) {
+                pt_triangle t;
+                if (jtv->kind != JValue::Obj || !get_vec3(c, jtv->get("a"), "triangle.a", t.a) ||
+                    !get_vec3(c, jtv->get("b"), "triangle.b", t.b) || !get_vec3(c, jtv->get("c"), "triangle.c", t.c)) {
+                    pt::set_error("scene: " + where + ": " + (c.err.empty() ? "bad triangle" : c.err));
+                    return PT_ERR_PARSE;
+                }
+                sc->triangles.push_back(t);
+            }
+        } else {
+            pt::set_error("scene: " + where + ": unknown variant `" + tag + "`");
+            return PT_ERR_PARSE;
+        }
+        sc->objects.push_back(o);
+    }
+    *out = sc.release();
+    return PT_OK;
+}
+
+void pt_scene_free(pt_scene *s) { delete s; }
+const char *pt_scene_id(const pt_scene *s) { return s ? s->id.c_str() : ""; }
+const pt_camera *pt_scene_camera(const pt_scene *s) { return s ? &s->camera : nullptr; }
+const pt_object *pt_scene_objects(const pt_scene *s, uint32_t *n) {
+    if (n) *n = s ? (uint32_t)s->objects.size() : 0;
+    return s ? s->objects.data() : nullptr;
+}
+const pt_triangle *pt_scene_triangles(const pt_scene *s, uint32_t *n) {
+    if (n) *n = s ? (uint32_t)s->triangles.size() : 0;
+    return s ? s->triangles.data() : nullptr;
+}
+
+float pt_gamma_correction(float x) {
+    const float c = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);  // f32::clamp keeps NaN
+    return powf(c, 1.0f / 2.2f);
+}
+
+uint32_t pt_to_int_with_gamma_correction(float x) {
+    const float v = 255.0f * pt_gamma_correction(x) + 0.5f;
+    if (!(v > 0.0f)) return 0;  // `as usize`: NaN and negatives -> 0
+    return (uint32_t)v;
+}
+
+int pt_write_ppm(const char *path, const float *rgb, uint32_t width, uint32_t height, uint32_t spp,
+                 const char *scene_id, uint64_t seconds) {
+    if (!path || !rgb || !scene_id) {
+        pt::set_error("NULL argument");
+        return PT_ERR_INVALID;
+    }
+    FILE *f = fopen(path, "wb");
+    if (!f) {
+        pt::set_error(std::string("cannot create ") + path);
+        return PT_ERR_IO;
+    }
+    std::string buf;
+    buf.reserve((size_t)width * height * 12 + 256);
+    char tmp[160];
+    buf += "P3\n";
+    buf += "# samplesPerPixel: " + std::to_string(spp) + ", resolution_y: " + std::to_string(height) +
+           ", scene_id: " + scene_id + "\n";
+    buf += "# rendering time: " + std::to_string(seconds) + " s\n";
+    buf += std::to_string(width) + " " + std::to_string(height) + "\n255\n";
+    const size_t npx = (size_t)width * height;
+    for (size_t i = npx; i-- > 0;) {  // pixels.iter().rev(), mod.rs:1065
+        int k = snprintf(tmp, sizeof tmp, "%u %u %u ", pt_to_int_with_gamma_correction(rgb[3 * i]),
+                         pt_to_int_with_gamma_correction(rgb[3 * i + 1]), pt_to_int_with_gamma_correction(rgb[3 * i + 2]));
+        buf.append(tmp, (size_t)k);
+    }
+    const size_t wr = fwrite(buf.data(), 1, buf.size(), f);
+    const int cl = fclose(f);
+    if (wr != buf.size() || cl != 0) {
+        pt::set_error(std::string("short write to ") + path);
+        return PT_ERR_IO;
+    }
+    return PT_OK;
+}
+
+}  // extern "C"

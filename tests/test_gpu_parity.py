@@ -1,0 +1,225 @@
+"""Parity of the HIP path (through the C ABI) with the oracle on the same seeded inputs.  -m gpu.
+
+Bars: geometry and control flow are bit-exact (hit distance/ids/points/normals, RNG words, bounce counts);
+radiance is summed top-down in 32.32 fixed point on the GPU and bottom-up in f32 by the reference, so the
+image is compared with the tolerance the north star states: 1e-4 per channel (observed ~1e-6)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ptlib
+from ptlib import PtConfig, PtStats, PtoConfig, _np_f
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+SCENES = ["single-sphere", "two-spheres", "three-spheres", "cartesian", "cornell", "mesh"]
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    L = ptlib.product()
+    assert L.pt_device_count() >= 1, "no HIP device visible: the product has no CPU fallback"
+    ctx = C.c_void_p()
+    rc = L.pt_ctx_create(0, C.byref(ctx))
+    assert rc == 0, L.pt_last_error()
+    yield L, ctx
+    L.pt_ctx_destroy(ctx)
+
+
+def set_scene(gpu, sc):
+    L, ctx = gpu
+    rc = L.pt_ctx_set_scene(ctx, C.byref(sc.cam), sc.objs, sc.n_objs, sc.tris, sc.n_tris)
+    assert rc == 0, L.pt_last_error()
+
+
+def gpu_render(gpu, sc, w, h, spp, seed, backend=0, band=None, rays_per_pass=0):
+    """pt_render: host buffers in and out, the drop-in entry point."""
+    L, _ = gpu
+    cfg = PtConfig(w, h, spp, backend, seed, 0, 0, rays_per_pass, 0)
+    if band:
+        cfg.idx_begin, cfg.idx_end = band
+    out = np.zeros((w * h, 3), dtype=np.float32)
+    st = PtStats()
+    rc = L.pt_render(C.byref(cfg), C.byref(sc.cam), sc.objs, sc.n_objs, sc.tris, sc.n_tris, _np_f(out), None, None,
+                     None, C.byref(st))
+    assert rc == 0, L.pt_last_error()
+    return out, st
+
+
+def test_device_numerics_contract(gpu):
+    """sin/cos/sqrt/reciprocal and Philox on the device are bit-identical to the oracle's host evaluation."""
+    L, ctx = gpu
+    O = ptlib.oracle()
+    rng = np.random.default_rng(0)
+    k = rng.integers(0, 1 << 24, size=200000, dtype=np.uint32)
+    two_pi = np.float32(2.0) * np.float32(3.141592653589793)
+    x = (two_pi * (k.astype(np.float32) * np.float32(1.0 / 16777216.0))).astype(np.float32)
+    x[:8] = [0.0, 1e-5, 0.25, 0.7853981, 0.7853982, 3.1415927, 6.2831845, 1.5707964]
+    n = len(x)
+    s, c, q, r = (np.zeros(n, np.float32) for _ in range(4))
+    ph = np.zeros(4 * n, np.uint32)
+    rc = L.pt_ctx_numerics_probe(ctx, _np_f(x), n, _np_f(s), _np_f(c), _np_f(q), _np_f(r),
+                                 ph.ctypes.data_as(ptlib.u32p))
+    assert rc == 0, L.pt_last_error()
+    want_s = np.array([O.pto_sinf(float(v)) for v in x[:20000]], np.float32)
+    want_c = np.array([O.pto_cosf(float(v)) for v in x[:20000]], np.float32)
+    assert np.array_equal(s[:20000].view(np.uint32), want_s.view(np.uint32))
+    assert np.array_equal(c[:20000].view(np.uint32), want_c.view(np.uint32))
+    # IEEE sqrt and division are correctly rounded on both sides: compare against numpy f32
+    assert np.array_equal(q.view(np.uint32), np.sqrt(x).view(np.uint32))
+    with np.errstate(divide="ignore"):
+        assert np.array_equal(r.view(np.uint32), (np.float32(1.0) / x).view(np.uint32))
+    out = (C.c_uint32 * 4)()
+    for i in list(range(64)) + [n - 1]:
+        ctr = (C.c_uint32 * 4)(i, int(x[i:i + 1].view(np.uint32)[0]), ((i << 8) | (i & 15)) & 0xffffffff, 0)
+        O.pto_philox4x32_10(ctr, (C.c_uint32 * 2)(0x89abcdef, 0x01234567), out)
+        assert list(out) == list(ph[4 * i:4 * i + 4])
+
+
+@pytest.mark.parametrize("sid", ["cornell", "mesh", "three-spheres"])
+def test_intersect_ray_by_ray(gpu, sid):
+    """Every ray the path tracer casts for a block of pixels: hit distance, object, triangle, hit point and
+    normal from the device intersection code are bit-identical to intersect_scene of the oracle."""
+    L, ctx = gpu
+    O = ptlib.oracle()
+    sc = ptlib.load_scene_py(ptlib.scene_path(sid))
+    set_scene(gpu, sc)
+    w, h, spp = 64, 48, 2 if sid == "mesh" else 8
+    cfg = PtoConfig(w, h, spp, 0, 11)
+    cap = w * h * spp * 16
+    rays = np.zeros((cap, 6), dtype=np.float32)
+    ps = sc.pto()
+    n = O.pto_dump_rays(C.byref(ps), C.byref(cfg), 0, w * h, _np_f(rays), cap)
+    assert 0 < n < cap
+    o = np.ascontiguousarray(rays[:n, :3])
+    d = np.ascontiguousarray(rays[:n, 3:])
+
+    def run(fn, handle):
+        t = np.zeros(n, np.float32)
+        oid = np.zeros(n, np.int32)
+        tid = np.zeros(n, np.int32)
+        x = np.zeros((n, 3), np.float32)
+        nr = np.zeros((n, 3), np.float32)
+        rc = fn(handle, _np_f(o), _np_f(d), n, _np_f(t), oid.ctypes.data_as(ptlib.i32p),
+                tid.ctypes.data_as(ptlib.i32p), _np_f(x), _np_f(nr))
+        return rc, t, oid, tid, x, nr
+
+    rc, t, oid, tid, x, nr = run(L.pt_ctx_intersect, ctx)
+    assert rc == 0, L.pt_last_error()
+    _, t0, oid0, tid0, x0, nr0 = run(O.pto_intersect_batch, C.byref(ps))
+    assert np.array_equal(oid, oid0)
+    assert np.array_equal(tid, tid0)
+    assert np.array_equal(t.view(np.uint32), t0.view(np.uint32))
+    assert np.array_equal(x.view(np.uint32), x0.view(np.uint32))
+    assert np.array_equal(nr.view(np.uint32), nr0.view(np.uint32))
+    assert (oid0 < 0).sum() > 0 or sid != "cornell"  # the closed box still leaks rays
+
+
+@pytest.mark.parametrize("backend", [ptlib.BACKEND_WAVEFRONT, ptlib.BACKEND_MEGAKERNEL])
+@pytest.mark.parametrize("sid", SCENES)
+def test_frame_parity(gpu, sid, backend):
+    sc = ptlib.load_scene_py(ptlib.scene_path(sid))
+    w, h, spp = (48, 32, 4) if sid == "mesh" else (96, 64, 16)
+    want, cnt, _ = ptlib.oracle_render(sc, w, h, spp, 3)
+    got, st = gpu_render(gpu, sc, w, h, spp, 3, backend)
+    assert st.ray_bounces == cnt.ray_bounces  # same number of intersect_scene calls: same paths
+    assert st.samples == w * h * spp
+    assert float(np.abs(got - want).max()) <= TOL
+
+
+def test_many_passes_and_odd_sizes(gpu):
+    """Passes of 1 spp, a width that is not a multiple of the wave, spp that is not a multiple of the pass."""
+    sc = ptlib.load_scene_py(ptlib.scene_path("cornell"))
+    w, h, spp = 67, 41, 7
+    want, cnt, _ = ptlib.oracle_render(sc, w, h, spp, 9)
+    got, st = gpu_render(gpu, sc, w, h, spp, 9, 0, rays_per_pass=2 * w * h)
+    assert st.passes == 4 and st.ray_bounces == cnt.ray_bounces
+    assert float(np.abs(got - want).max()) <= TOL
+    got1, st1 = gpu_render(gpu, sc, w, h, spp, 9, 0, rays_per_pass=1)
+    assert st1.passes == 7
+    assert np.array_equal(got1, got)  # the image does not depend on the pass size (integer accumulation)
+
+
+def test_bands_equal_whole_frame(gpu):
+    """Rendering the frame as N bands (what N ranks do) gives bit-identical pixels to one call."""
+    sc = ptlib.load_scene_py(ptlib.scene_path("cornell"))
+    w, h, spp = 80, 60, 8
+    whole, st = gpu_render(gpu, sc, w, h, spp, 4)
+    for backend in (0, 1):
+        for n in (2, 3, 8):
+            img = np.zeros_like(whole)
+            total = 0
+            for r in range(n):
+                b, e = (w * h * r) // n, (w * h * (r + 1)) // n
+                part, s = gpu_render(gpu, sc, w, h, spp, 4, backend, band=(b, e))
+                img[b:e] = part[b:e]
+                assert not part[:b].any() and not part[e:].any()
+                total += s.ray_bounces
+            assert np.array_equal(img, whole)
+            assert total == st.ray_bounces
+
+
+def test_single_sphere_analytic(gpu):
+    """single-sphere.json: pixels inside the silhouette are exactly 1.0 (emission clamps), background 0.0."""
+    sc = ptlib.load_scene_py(ptlib.scene_path("single-sphere"))
+    got, st = gpu_render(gpu, sc, 256, 256, 64, 1)
+    vals = np.unique(got)
+    assert vals.min() == 0.0 and vals.max() == 1.0
+    frac = ((got > 0) & (got < 1)).any(axis=1).mean()
+    assert frac < 0.05  # only silhouette pixels are fractional
+    assert (got == 1.0).all(axis=1).mean() > 0.05
+
+
+def test_errors_and_cancel(gpu):
+    L, ctx = gpu
+    sc = ptlib.load_scene_py(ptlib.scene_path("cornell"))
+    out = np.zeros((16 * 16, 3), np.float32)
+    st = PtStats()
+    bad = PtConfig(0, 16, 4, 0, 1, 0, 0, 0, 0)
+    assert L.pt_render(C.byref(bad), C.byref(sc.cam), sc.objs, sc.n_objs, sc.tris, sc.n_tris, _np_f(out), None, None,
+                       None, C.byref(st)) == -1
+    bad = PtConfig(16, 16, 4, 7, 1, 0, 0, 0, 0)
+    assert L.pt_render(C.byref(bad), C.byref(sc.cam), sc.objs, sc.n_objs, sc.tris, sc.n_tris, _np_f(out), None, None,
+                       None, C.byref(st)) == -1
+    bad = PtConfig(16, 16, 4, 0, 1, 10, 300, 0, 0)
+    assert L.pt_render(C.byref(bad), C.byref(sc.cam), sc.objs, sc.n_objs, sc.tris, sc.n_tris, _np_f(out), None, None,
+                       None, C.byref(st)) == -1
+    # cancel flag already set: PT_CANCELLED, framebuffer all zero (the reference leaves unrendered pixels 0)
+    flag = (C.c_uint8 * 1)(1)
+    cfg = PtConfig(16, 16, 4, 0, 1, 0, 0, 0, 0)
+    rc = L.pt_render(C.byref(cfg), C.byref(sc.cam), sc.objs, sc.n_objs, sc.tris, sc.n_tris, _np_f(out),
+                     C.cast(flag, C.c_void_p), None, None, C.byref(st))
+    assert rc == -4 and not out.any()
+    # progress callback reaches 1.0
+    seen = []
+    cb = ptlib.PROGRESS_FN(lambda user, frac: seen.append(frac))
+    rc = L.pt_render(C.byref(cfg), C.byref(sc.cam), sc.objs, sc.n_objs, sc.tris, sc.n_tris, _np_f(out), None,
+                     C.cast(cb, C.c_void_p), None, C.byref(st))
+    assert rc == 0 and seen and seen[-1] == 1.0
+
+
+def test_full_size_properties(gpu):
+    """BASELINE size (cornell 1024x768), reduced spp: determinism, backend agreement, bounce statistics and
+    frame mean against the survey's strict-f32 probe (sanity, MC noise ~0.002)."""
+    sc = ptlib.load_scene_py(ptlib.scene_path("cornell"))
+    w, h, spp = 1024, 768, 32
+    a, sa = gpu_render(gpu, sc, w, h, spp, 1, 0)
+    b, sb = gpu_render(gpu, sc, w, h, spp, 1, 0)
+    m, sm = gpu_render(gpu, sc, w, h, spp, 1, 1)
+    assert np.array_equal(a, b) and sa.ray_bounces == sb.ray_bounces
+    assert np.array_equal(a, m) and sa.ray_bounces == sm.ray_bounces
+    per_sample = sa.ray_bounces / (w * h * spp)
+    assert 8.5 < per_sample < 8.85, per_sample  # 8.68 in the survey probe
+    # a sample of pixels against the oracle at full resolution
+    O = ptlib.oracle()
+    ps = sc.pto()
+    cfg = PtoConfig(w, h, spp, 0, 1)
+    rng = np.random.default_rng(5)
+    px = np.zeros(3, np.float32)
+    worst = 0.0
+    for idx in rng.integers(0, w * h, size=300):
+        O.pto_render_pixel(C.byref(ps), C.byref(cfg), int(idx), _np_f(px), None)
+        worst = max(worst, float(np.abs(px - a[idx]).max()))
+    assert worst <= TOL, worst
