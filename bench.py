@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py — ray-bounces/s of the radiance() hot path on MI355X.
+
+One step = one whole frame of BASELINE.json's metric workload (scenes/cornell.json, 1024x768, 4096 spp by
+default) rendered by the wavefront HIP pipeline through the C ABI, the scene already resident in HBM.
+With N ranks (one process per GPU, launched by torch.distributed.run) the frame is cut into N contiguous
+bands of framebuffer indices, every rank renders its band, and one RCCL all-gather assembles the image:
+total work is fixed, so scaling is "strong".  value = ray bounces of all ranks / max-over-ranks time.
+
+The JSON line also carries
+  roofline      the intersect kernel: algorithmic 32 B per ray (24 B ray in + 8 B hit out) times the rays its
+                launches processed, divided by the HIP-event time of those launches measured live in the
+                timed region, against the 8 TB/s HBM peak;
+  cpu_baseline  the oracle (CPU port of the reference's rayon loop; the Rust reference cannot be built in
+                this image) timed on this box's host cores on a bounded sample of the same workload;
+  variants      the persistent megakernel backend on the same frame.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+INTERSECT_BYTES_PER_RAY = 32  # 24 B (o, d) read + 8 B (t, id) written
+
+
+def host_cpu_share(limit):
+    """Threads this process may really use: min(OpenMP default, affinity mask, cgroup cpu quota)."""
+    n = limit
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    env = os.environ.get("PT_CPU_THREADS")
+    if env:
+        n = int(env)
+    return max(1, n)
+
+
+def cpu_baseline(width, height, seed, budget_spp):
+    """Time the oracle (tests-only CPU restatement) on all host cores on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ptlib
+
+    sc = ptlib.load_scene_py(ptlib.scene_path("cornell"))
+    threads = host_cpu_share(ptlib.oracle().pto_max_threads())
+    _, cnt, secs = ptlib.oracle_render(sc, width, height, budget_spp, seed, threads=threads)
+    _, cnt1, secs1 = ptlib.oracle_render(sc, width, height, 1, seed, threads=1)
+    return {
+        "value": cnt.ray_bounces / secs,
+        "unit": "ray-bounces/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "cornell.json %dx%d @%dspp (same scene and resolution, spp cut from the GPU run's; cost is "
+                  "linear in spp), OpenMP dynamic over shuffled pixels = the reference's rayon loop" %
+                  (width, height, budget_spp),
+        "single_core_value": cnt1.ray_bounces / secs1,
+        "seconds": secs,
+        "note": "C restatement of the reference's CPU path (no Rust toolchain in this image)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=4096)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--height", type=int, default=768)
+    ap.add_argument("--scene", default="cornell")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--rays-per-pass", type=int, default=0)
+    ap.add_argument("--backend", default="wavefront", choices=["wavefront", "megakernel"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--cpu-spp", type=int, default=16)
+    args = ap.parse_args()
+
+    import torch
+
+    pkg = importlib.import_module("path-tracer-rust_amd")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    W, H, spp = args.width, args.height, args.spp
+    npix = W * H
+    scene = pkg.Scene(os.path.join(ROOT, "scenes", args.scene + ".json"), ROOT)
+    ctx = pkg.Context(local_rank)
+    ctx.set_scene(scene)  # scene tables resident in HBM before the timed region
+    band = pkg.band_for_rank(npix, rank, world)
+    local = torch.zeros((band[1] - band[0], 3), dtype=torch.float32, device=dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(backend, profile):
+        ctx.set_profiling(profile)
+        st = ctx.render(local.data_ptr(), W, H, spp, seed=args.seed, backend=backend, band=band,
+                        rays_per_pass=args.rays_per_pass)
+        full = pkg.gather_bands(local, npix, rank, world, dist)
+        return st, full
+
+    def timed(backend, steps, warmup, profile):
+        for _ in range(warmup):
+            step(backend, profile)
+        barrier()
+        t0 = time.perf_counter()
+        bounces = isect_rays = 0
+        isect_ms = 0.0
+        launches = 0
+        for _ in range(steps):
+            st, full = step(backend, profile)
+            bounces += st.ray_bounces
+            isect_rays += st.intersect_rays
+            isect_ms += st.ms_intersect
+            launches += st.intersect_launches
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            b = torch.tensor([bounces], dtype=torch.int64, device=dev)
+            dist.all_reduce(b, op=dist.ReduceOp.SUM)
+            bounces = int(b.item())
+        return dict(dt=dt, bounces=bounces, isect_rays=isect_rays, isect_ms=isect_ms, launches=launches, image=full)
+
+    main_run = timed(args.backend, args.steps, args.warmup, profile=(args.backend == "wavefront"))
+    value = main_run["bounces"] / main_run["dt"]
+    out = {
+        "metric": "ray_bounces_per_sec",
+        "value": value,
+        "unit": "ray-bounces/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * main_run["dt"] / args.steps,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "scenes/%s.json %dx%d @%dspp, wavefront HIP pipeline, %d band(s) + RCCL all-gather"
+                        % (args.scene, W, H, spp, world),
+            "backend": args.backend,
+            "width": W, "height": H, "spp": spp, "seed": args.seed,
+            "ray_bounces_per_frame": main_run["bounces"] // max(1, args.steps),
+        },
+    }
+    if args.backend == "wavefront" and main_run["isect_ms"] > 0:
+        # rank 0's intersect launches (every rank runs the same kernel on its own band)
+        achieved = INTERSECT_BYTES_PER_RAY * main_run["isect_rays"] / (main_run["isect_ms"] * 1e-3) / 1e9
+        out["roofline"] = {
+            "kernel": "k_intersect",
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "bytes_per_ray": INTERSECT_BYTES_PER_RAY,
+            "rays_per_launch": main_run["isect_rays"] / max(1, main_run["launches"]),
+            "avg_launch_ms": main_run["isect_ms"] / max(1, main_run["launches"]),
+            "intersect_rays_per_s": main_run["isect_rays"] / (main_run["isect_ms"] * 1e-3),
+            "launches": main_run["launches"],
+        }
+        prof = os.path.join(ROOT, "profiles", "r01_intersect_traffic.json")
+        if os.path.exists(prof):
+            try:
+                with open(prof) as f:
+                    tr = json.load(f)
+                out["roofline"]["traffic"] = tr.get("hbm_bytes_per_launch")
+                out["roofline"]["traffic_source"] = tr.get("source")
+            except Exception:
+                pass
+    if rank == 0 and world == 1 and not args.no_variants:
+        other = "megakernel" if args.backend == "wavefront" else "wavefront"
+        v = timed(other, max(1, min(args.steps, 2)), 1, profile=False)
+        same = bool(torch.equal(v["image"], main_run["image"]))
+        out["variants"] = {other: {"value": v["bounces"] / v["dt"], "unit": "ray-bounces/s",
+                                   "ms_per_step": 1e3 * v["dt"] / max(1, min(args.steps, 2)),
+                                   "image_identical_to_main_backend": same}}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(W, H, args.seed, args.cpu_spp)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

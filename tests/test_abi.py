@@ -1,0 +1,116 @@
+"""No-GPU checks of the boundary: the C-ABI library loads, exports every symbol include/ptrace.h declares,
+and its host-only entry points (camera basis, Mesh::new bounds, gamma, PPM bytes) agree with the oracle.
+No compute entry point is called with real work here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import ptlib
+from ptlib import _np_f
+
+L = ptlib.product()
+O = ptlib.oracle()
+HEADER = os.path.join(ptlib.ROOT, "include", "ptrace.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b(pt_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(n for n in names if n not in ("pt_progress_fn",)))
+
+
+def test_every_declared_symbol_is_exported():
+    names = declared_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(L, n), "libptrace_hip.so does not export " + n
+
+
+def test_version_and_struct_sizes():
+    assert L.pt_abi_version() == 1
+    assert b"gfx950" in L.pt_version()
+    # POD layout the Rust/cgo/ctypes side must match (include/ptrace.h)
+    assert C.sizeof(ptlib.PtCamera) == 36
+    assert C.sizeof(ptlib.PtTriangle) == 36
+    assert C.sizeof(ptlib.PtObject) == 72
+    assert C.sizeof(ptlib.PtConfig) == 40
+    assert C.sizeof(ptlib.PtStats) == 56
+
+
+def test_no_device_means_error_not_fallback():
+    """Without a GPU the compute entry points refuse to run (there is no CPU path in the product)."""
+    if L.pt_device_count() > 0:
+        pytest.skip("a GPU is present")
+    ctx = C.c_void_p()
+    assert L.pt_ctx_create(0, C.byref(ctx)) == -2  # PT_ERR_NO_DEVICE
+    assert b"no HIP device" in L.pt_last_error()
+    sc = ptlib.load_scene_py(ptlib.scene_path("single-sphere"))
+    cfg = ptlib.PtConfig(8, 8, 1, 0, 1, 0, 0, 0, 0)
+    out = np.full((64, 3), 7.0, np.float32)
+    st = ptlib.PtStats()
+    rc = L.pt_render(C.byref(cfg), C.byref(sc.cam), sc.objs, sc.n_objs, sc.tris, sc.n_tris, _np_f(out), None, None,
+                     None, C.byref(st))
+    assert rc == -2 and (out == 7.0).all()
+
+
+@pytest.mark.parametrize("sid", ["cornell", "mesh"])
+def test_camera_basis_matches_oracle(sid):
+    sc = ptlib.load_scene_py(ptlib.scene_path(sid))
+    a = [(C.c_float * 3)() for _ in range(3)]
+    b = [(C.c_float * 3)() for _ in range(3)]
+    assert L.pt_camera_basis(C.byref(sc.cam), *a) == 0
+    O.pto_camera_basis(C.byref(sc.cam), *b)
+    for x, y in zip(a, b):
+        assert bytes(x) == bytes(y)
+
+
+def test_mesh_bounding_sphere_matches_oracle_and_reference_data():
+    sc = ptlib.load_scene_py(ptlib.scene_path("cornell"))
+    for i in range(sc.n_objs):
+        o = sc.objs[i]
+        if o.kind != ptlib.PT_MESH:
+            continue
+        arr = (ptlib.PtTriangle * o.tri_count)(*[sc.tris[o.tri_offset + k] for k in range(o.tri_count)])
+        ctr, rad = (C.c_float * 3)(), C.c_float()
+        assert L.pt_mesh_bounding_sphere(arr, o.tri_count, ctr, C.byref(rad)) == 0
+        assert list(ctr) == list(o.bs_center) and rad.value == o.bs_radius  # values serialised by the reference
+
+
+def test_gamma_kats_and_oracle_agreement():
+    for x, want in [(0.0, 0), (0.5, 186), (0.75, 224), (1.0, 255)]:  # src/render/test.rs:29-35
+        assert L.pt_to_int_with_gamma_correction(x) == want
+    xs = np.concatenate([np.linspace(-0.5, 1.5, 4001), [np.nan, np.inf, -np.inf]]).astype(np.float32)
+    for x in xs:
+        assert L.pt_to_int_with_gamma_correction(float(x)) == O.pto_to_int_with_gamma_correction(float(x))
+
+
+def test_ppm_bytes_match_oracle(tmp_path):
+    """P3 writer (mod.rs:1043-1076): header lines, reversed pixel order, trailing space, no final newline."""
+    rng = np.random.default_rng(1)
+    w, h = 7, 5
+    img = rng.uniform(-0.2, 1.3, size=(w * h, 3)).astype(np.float32)
+    img[3] = [np.nan, 0.0, 1.0]
+    path = str(tmp_path / "x.ppm")
+    assert L.pt_write_ppm(path.encode(), _np_f(img), w, h, 12, b"cornell", 3) == 0
+    got = open(path, "rb").read()
+    n = O.pto_format_ppm(_np_f(img), w, h, 12, b"cornell", 3, None, 0)
+    buf = C.create_string_buffer(n)
+    O.pto_format_ppm(_np_f(img), w, h, 12, b"cornell", 3, buf, n)
+    assert got == buf.raw
+    assert got.startswith(b"P3\n# samplesPerPixel: 12, resolution_y: 5, scene_id: cornell\n# rendering time: 3 s\n7 5\n255\n")
+    assert got.endswith(b" ") and got.count(b"\n") == 5
+    # first pixel written is the LAST framebuffer entry
+    body = got.split(b"255\n", 1)[1].split()
+    assert [int(v) for v in body[:3]] == [O.pto_to_int_with_gamma_correction(float(v)) for v in img[-1]]
+
+
+def test_invalid_arguments_return_codes():
+    assert L.pt_camera_basis(None, None, None, None) == -1
+    assert L.pt_mesh_bounding_sphere(None, 0, None, None) == -1
+    h = C.c_void_p()
+    assert L.pt_scene_load(b"/nonexistent/x.json", b".", C.byref(h)) == -6
+    assert L.pt_write_ppm(b"/nonexistent_dir/x.ppm", _np_f(np.zeros(3, np.float32)), 1, 1, 1, b"s", 0) == -6

@@ -1,0 +1,68 @@
+"""The N>1 path on CPU: two gloo ranks each take the band the harness assigns (band_for_rank), fill it (with
+the oracle standing in for the GPU render — test infrastructure), and one all-gather (gather_bands, the same
+function bench.py calls over RCCL) must reproduce the single-rank image exactly."""
+import importlib
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import ptlib
+
+pkg = importlib.import_module("path-tracer-rust_amd")
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, w, h, spp, seed, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sc = ptlib.load_scene_py(ptlib.scene_path("cornell"))
+        npix = w * h
+        b, e = pkg.band_for_rank(npix, rank, world)
+        img, cnt, _ = ptlib.oracle_render(sc, w, h, spp, seed, idx_begin=b, idx_end=e, threads=2)
+        local = torch.from_numpy(img[b:e].copy())
+        full = pkg.gather_bands(local, npix, rank, world, dist)
+        total = torch.tensor([cnt.ray_bounces], dtype=torch.int64)
+        dist.all_reduce(total)
+        np.save(os.path.join(out_dir, "rank%d.npy" % rank), full.numpy())
+        if rank == 0:
+            np.save(os.path.join(out_dir, "bounces.npy"), total.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("w,h,world", [(32, 24, 2), (31, 23, 2), (30, 7, 3)])
+def test_two_rank_bands_reassemble_the_frame(tmp_path, w, h, world):
+    spp, seed = 2, 6
+    mp.spawn(_worker, args=(world, free_port(), w, h, spp, seed, str(tmp_path)), nprocs=world, join=True)
+    sc = ptlib.load_scene_py(ptlib.scene_path("cornell"))
+    want, cnt, _ = ptlib.oracle_render(sc, w, h, spp, seed, threads=2)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), "rank%d.npy" % r))
+        assert got.shape == want.shape and np.array_equal(got, want)
+    assert int(np.load(os.path.join(str(tmp_path), "bounces.npy"))[0]) == cnt.ray_bounces
+
+
+def test_band_partition_properties():
+    for npix in (1, 7, 786432, 4096 * 4096):
+        for world in (1, 2, 3, 4, 8):
+            bands = [pkg.band_for_rank(npix, r, world) for r in range(world)]
+            assert bands[0][0] == 0 and bands[-1][1] == npix
+            assert all(bands[i][1] == bands[i + 1][0] for i in range(world - 1))
+            sizes = [e - b for b, e in bands]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        pkg.band_for_rank(10, 3, 2)

@@ -1,0 +1,157 @@
+"""The formats either side of the path: the product's C++ JSON/OFF loader against an independent Python
+reading of the same files, the committed scene fixtures against the reference's own data files (when the
+reference tree is mounted), and the loader's error behaviour where the reference panics."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import ptlib
+
+L = ptlib.product()
+SCENES = ["single-sphere", "two-spheres", "three-spheres", "cartesian", "cornell", "mesh"]
+REF = "/root/reference"
+
+
+def load_c(path, base=None):
+    h = C.c_void_p()
+    rc = L.pt_scene_load(path.encode(), (base or ptlib.ROOT).encode(), C.byref(h))
+    return rc, h
+
+
+def as_bytes(arr, n):
+    return bytes(C.cast(arr, C.POINTER(C.c_char * (C.sizeof(arr._type_) * n))).contents) if n else b""
+
+
+@pytest.mark.parametrize("sid", SCENES)
+def test_cpp_loader_equals_python_loader(sid):
+    rc, h = load_c(ptlib.scene_path(sid))
+    assert rc == 0, L.pt_last_error()
+    py = ptlib.load_scene_py(ptlib.scene_path(sid))
+    n, m = C.c_uint32(), C.c_uint32()
+    objs = L.pt_scene_objects(h, C.byref(n))
+    tris = L.pt_scene_triangles(h, C.byref(m))
+    assert L.pt_scene_id(h).decode() == py.id == sid
+    assert (n.value, m.value) == (py.n_objs, py.n_tris)
+    assert bytes(L.pt_scene_camera(h).contents) == bytes(py.cam)
+    assert as_bytes(objs, n.value) == bytes(py.objs)[: C.sizeof(ptlib.PtObject) * n.value]
+    assert as_bytes(tris, m.value) == bytes(py.tris)[: C.sizeof(ptlib.PtTriangle) * m.value]
+    L.pt_scene_free(h)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not mounted (GPU box)")
+@pytest.mark.parametrize("sid", SCENES)
+def test_committed_fixtures_equal_reference_data(sid):
+    """scenes/*.json in this repo are compact re-emissions of the reference's data files: every number must
+    parse to the same f32 (via f64, as serde_json does) and the structure must be identical."""
+    def f32ify(o):
+        if isinstance(o, float):
+            return float(np.float32(o))
+        if isinstance(o, list):
+            return [f32ify(x) for x in o]
+        if isinstance(o, dict):
+            return {k: f32ify(v) for k, v in o.items()}
+        return o
+    ours = json.load(open(ptlib.scene_path(sid)))
+    theirs = json.load(open(os.path.join(REF, "scenes", sid + ".json")))
+    assert f32ify(ours) == f32ify(theirs)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not mounted (GPU box)")
+def test_committed_mesh_equals_reference_mesh():
+    a = ptlib.load_off_py(os.path.join(ptlib.ROOT, "meshes", "mctri.off"), 0.16)
+    b = ptlib.load_off_py(os.path.join(REF, "meshes", "mctri.off"), 0.16)
+    assert len(a) == len(b) == 810
+    for ta, tb in zip(a, b):
+        for va, vb in zip(ta, tb):
+            assert va.tobytes() == vb.tobytes()
+
+
+def test_mesh_scene_facts():
+    """mctri.off at scale 0.16 -> bounding sphere c=(0.24,0.64,-0.16) r=1.60997; 824 triangles."""
+    rc, h = load_c(ptlib.scene_path("mesh"))
+    assert rc == 0
+    n, m = C.c_uint32(), C.c_uint32()
+    objs = L.pt_scene_objects(h, C.byref(n))
+    L.pt_scene_triangles(h, C.byref(m))
+    assert (n.value, m.value) == (8, 824)
+    assert objs[0].tri_count == 810 and objs[0].kind == ptlib.PT_MESH
+    assert np.allclose(list(objs[0].bs_center), [0.24, 0.64, -0.16], atol=1e-6)
+    assert abs(objs[0].bs_radius - 1.60997) < 1e-5
+    L.pt_scene_free(h)
+
+
+def write(tmp_path, name, text):
+    p = tmp_path / name
+    p.write_text(text)
+    return str(p)
+
+
+GOOD_CAM = '"camera":{"position":[0,0,1],"direction":[0,0,-1],"focal_length":0.035,"sensor_width":0.036,"aspect_ratio":1.5}'
+GOOD_MAT = '"material":{"color":[1,1,1],"emmission":[0,0,0],"reflect_type":"Diffuse"}'
+
+
+def test_loader_accepts_pretty_json_unknown_keys_and_escapes(tmp_path):
+    text = '{\n "id" : "a\\u0041\\n", "extra": {"x":[1,2,{"y":null}]},\n "objects": [ {"type_": {"Sphere": {"radius": 1e0}}, ' \
+           '"position": [1.5, -2, 3E-1], ' + GOOD_MAT + ', "unknown": true} ],\n ' + GOOD_CAM[:-1] + ',"updating_direction":null}\n}\n'
+    rc, h = load_c(write(tmp_path, "s.json", text))
+    assert rc == 0, L.pt_last_error()
+    assert L.pt_scene_id(h) == b"aA\n"
+    n = C.c_uint32()
+    o = L.pt_scene_objects(h, C.byref(n))
+    assert n.value == 1 and o[0].radius == 1.0 and list(o[0].position) == [1.5, -2.0, float(np.float32(0.3))]
+    L.pt_scene_free(h)
+
+
+@pytest.mark.parametrize("text", [
+    "",                                                     # empty file
+    "{",                                                    # truncated
+    '{"id":"x","objects":[],' + GOOD_CAM + '} trailing',    # trailing characters
+    '{"id":"x","objects":[]}',                              # missing camera (serde: missing field)
+    '{"id":"x","objects":[{"type_":{"Cube":{}},"position":[0,0,0],' + GOOD_MAT + '}],' + GOOD_CAM + '}',
+    '{"id":"x","objects":[{"type_":{"Sphere":{}},"position":[0,0,0],' + GOOD_MAT + '}],' + GOOD_CAM + '}',
+    '{"id":"x","objects":[{"type_":{"Sphere":{"radius":1}},"position":[0,0],' + GOOD_MAT + '}],' + GOOD_CAM + '}',
+    '{"id":"x","objects":[{"type_":{"Sphere":{"radius":1}},"position":[0,0,0],"material":{"color":[1,1,1],'
+    '"emmission":[0,0,0],"reflect_type":"Glossy"}}],' + GOOD_CAM + '}',
+    '{"id":"x","objects":[{"type_":{"Mesh":{"triangles":[]}},"position":[0,0,0],' + GOOD_MAT + '}],' + GOOD_CAM + '}',
+])
+def test_loader_rejects_what_serde_rejects(tmp_path, text):
+    rc, h = load_c(write(tmp_path, "bad.json", text))
+    assert rc == -7, (rc, L.pt_last_error())
+    assert not h.value
+
+
+def test_off_loader_semantics(tmp_path):
+    """load_off.rs: blank and '#' lines skipped anywhere, `OFF` header, vertex*scale, colour tokens after the
+    4th face token ignored, non-triangles rejected."""
+    good = "# c\nOFF\n\n# c2\n3 1 0\n0 0 0\n 1.0e+00 0 0 \n0 2 0\n# mid\n3 0 1 2 0.5 0.5 0.5 1.0\n"
+    tris = C.POINTER(ptlib.PtTriangle)()
+    n = C.c_uint32()
+    assert L.pt_load_off(write(tmp_path, "g.off", good).encode(), 0.5, C.byref(tris), C.byref(n)) == 0
+    assert n.value == 1 and list(tris[0].b) == [0.5, 0.0, 0.0] and list(tris[0].c) == [0.0, 1.0, 0.0]
+    L.pt_free(tris)
+    bad = {
+        "header": "COFF\n3 1 0\n0 0 0\n1 0 0\n0 1 0\n3 0 1 2\n",
+        "counts": "OFF\n3 1\n0 0 0\n1 0 0\n0 1 0\n3 0 1 2\n",
+        "vertex": "OFF\n3 1 0\n0 0\n1 0 0\n0 1 0\n3 0 1 2\n",
+        "vertex_tok": "OFF\n3 1 0\n0 0 x\n1 0 0\n0 1 0\n3 0 1 2\n",
+        "quad": "OFF\n4 1 0\n0 0 0\n1 0 0\n1 1 0\n0 1 0\n4 0 1 2 3\n",
+        "short_face": "OFF\n3 1 0\n0 0 0\n1 0 0\n0 1 0\n3 0 1\n",
+        "index": "OFF\n3 1 0\n0 0 0\n1 0 0\n0 1 0\n3 0 1 7\n",
+        "eof": "OFF\n3 2 0\n0 0 0\n1 0 0\n0 1 0\n3 0 1 2\n",
+    }
+    for name, text in bad.items():
+        rc = L.pt_load_off(write(tmp_path, name + ".off", text).encode(), 1.0, C.byref(tris), C.byref(n))
+        assert rc == -7, (name, rc)
+    assert L.pt_load_off(b"/nonexistent.off", 1.0, C.byref(tris), C.byref(n)) == -6
+
+
+def test_hdodec_style_pentagons_are_rejected(tmp_path):
+    """The reference cannot load meshes/hdodec.off (pentagon faces, load_off.rs:73-76); neither can we."""
+    text = "OFF\n5 1 0\n0 0 0\n1 0 0\n1 1 0\n0.5 1.5 0\n0 1 0\n5 0 1 2 3 4\n"
+    tris = C.POINTER(ptlib.PtTriangle)()
+    n = C.c_uint32()
+    assert L.pt_load_off(write(tmp_path, "p.off", text).encode(), 1.0, C.byref(tris), C.byref(n)) == -7
+    assert b"Invalid face" in L.pt_last_error()
