@@ -63,7 +63,7 @@ struct pt_ctx {
     pt_camera cam{};
     DevScene scene{};
     DevBuf<ObjRec> d_objs;
-    DevBuf<TriRec> d_tris;
+    DevBuf<TriPairRec> d_tris;
     DevBuf<MatRec> d_mats;
     DevBuf<TriShade> d_tshade;
     // wavefront queues
@@ -436,21 +436,22 @@ int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uin
     }
     HIP_TRY(hipSetDevice(c->device));
     int rc;
-    if ((rc = c->d_objs.ensure(fs.objs.size())) || (rc = c->d_tris.ensure(fs.tris.size())) ||
+    if ((rc = c->d_objs.ensure(fs.objs.size())) || (rc = c->d_tris.ensure(fs.tri_pairs.size())) ||
         (rc = c->d_mats.ensure(fs.mats.size())) || (rc = c->d_tshade.ensure(fs.tri_shade.size())))
         return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (!fs.objs.empty())
         HIP_TRY(hipMemcpy(c->d_objs.p, fs.objs.data(), fs.objs.size() * sizeof(ObjRec), hipMemcpyHostToDevice));
-    if (!fs.tris.empty())
-        HIP_TRY(hipMemcpy(c->d_tris.p, fs.tris.data(), fs.tris.size() * sizeof(TriRec), hipMemcpyHostToDevice));
+    if (!fs.tri_pairs.empty())
+        HIP_TRY(hipMemcpy(c->d_tris.p, fs.tri_pairs.data(), fs.tri_pairs.size() * sizeof(TriPairRec),
+                          hipMemcpyHostToDevice));
     if (!fs.mats.empty())
         HIP_TRY(hipMemcpy(c->d_mats.p, fs.mats.data(), fs.mats.size() * sizeof(MatRec), hipMemcpyHostToDevice));
     if (!fs.tri_shade.empty())
         HIP_TRY(hipMemcpy(c->d_tshade.p, fs.tri_shade.data(), fs.tri_shade.size() * sizeof(TriShade),
                           hipMemcpyHostToDevice));
     c->scene.objs = c->d_objs.p;
-    c->scene.tris = c->d_tris.p;
+    c->scene.tri_pairs = c->d_tris.p;
     c->scene.mats = c->d_mats.p;
     c->scene.tri_shade = c->d_tshade.p;
     c->scene.n_objs = n_objs;

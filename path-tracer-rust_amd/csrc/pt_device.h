@@ -30,17 +30,24 @@ struct alignas(16) ObjRec {
     float cx, cy, cz;    // sphere: position; mesh: bounding_sphere.position + position (mod.rs:268)
     float rr;            // radius.powi(2) of that sphere (mod.rs:416)
     uint32_t kind;       // kKindSphere / kKindMesh
-    uint32_t tri_begin;  // first record in the flattened triangle table
+    uint32_t tri_begin;   // first triangle of the mesh in the flattened triangle numbering
     uint32_t tri_count;
-    uint32_t pad;
+    uint32_t pair_begin;  // first TriPairRec of the mesh; it has (tri_count+1)/2 of them
 };
 
-// one record per triangle (world space), read with wave-uniform index
-struct alignas(16) TriRec {
-    float ax, ay, az;     // tri.a + offset                   (mod.rs:548)
-    float e1x, e1y, e1z;  // va_vb = (tri.b+offset) - (tri.a+offset)   (mod.rs:560)
-    float e2x, e2y, e2z;  // va_vc                             (mod.rs:561)
-    float pad0, pad1, pad2;
+// Two consecutive triangles of one mesh (world space), component by component, read with a wave-uniform
+// index.  Each component pair sits in two adjacent dwords, so after the scalar load it is an aligned SGPR
+// pair and can be the scalar operand of a packed VALU instruction (v_pk_mul_f32 / v_pk_add_f32): one ray is
+// tested against both triangles with one instruction per arithmetic step.  On gfx950 a VALU instruction
+// occupies its SIMD for 4 cycles whether it is packed or not (measured: profiles/README.md), so packing
+// halves the issue slots of the Moller-Trumbore arithmetic; every half is still an IEEE mul/add/sub.
+// A mesh with an odd triangle count gets an all-zero second triangle: its determinant is 0, which the
+// reference's first test rejects (mod.rs:571).
+struct alignas(16) TriPairRec {
+    float ax[2], ay[2], az[2];     // tri.a + offset                            (mod.rs:548)
+    float e1x[2], e1y[2], e1z[2];  // va_vb = (tri.b+offset) - (tri.a+offset)   (mod.rs:560)
+    float e2x[2], e2y[2], e2z[2];  // va_vc                                      (mod.rs:561)
+    float pad[2];
 };
 
 // per-object material record, gathered per lane in shade
@@ -59,7 +66,7 @@ struct alignas(16) TriShade {
 
 struct DevScene {
     const ObjRec *objs;
-    const TriRec *tris;
+    const TriPairRec *tri_pairs;
     const MatRec *mats;
     const TriShade *tri_shade;
     uint32_t n_objs;
@@ -93,6 +100,18 @@ struct HitRec {
 
 #if defined(__HIPCC__)
 
+// two f32 lanes per register pair: arithmetic on it compiles to v_pk_mul_f32 / v_pk_add_f32 (each half an
+// IEEE operation, no fusion under -ffp-contract=off)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 splat2(float v) {
+    f32x2 r = {v, v};
+    return r;
+}
+__device__ __forceinline__ f32x2 ld2(const float (&p)[2]) {
+    f32x2 r = {p[0], p[1]};
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // closest hit.  Objects in reverse index order, strict '<' (ties keep the higher object index,
 // mod.rs:637,649); inside a mesh the first triangle in list order wins ties (mod.rs:598).
@@ -121,24 +140,33 @@ __device__ __forceinline__ HitRec intersect_scene_dev(const DevScene &S, vec3 o,
             if (__builtin_amdgcn_ballot_w64(sph_hit) != 0ull) {
                 float mt = __builtin_inff();
                 int32_t mid = -1;
-                const uint32_t kb = ob.tri_begin, ke = ob.tri_begin + ob.tri_count;
-                for (uint32_t k = kb; k < ke; ++k) {
-                    const TriRec tr = S.tris[k];  // wave-uniform -> scalar loads
-                    const vec3 e1 = mk(tr.e1x, tr.e1y, tr.e1z), e2 = mk(tr.e2x, tr.e2y, tr.e2z);
-                    const vec3 pvec = cross(d, e2);
-                    const float determinant = dot(e1, pvec);
-                    const float inv_det = 1.0f / determinant;
-                    const vec3 tvec = o - mk(tr.ax, tr.ay, tr.az);
-                    const float u = dot(tvec, pvec) * inv_det;
-                    const vec3 qvec = cross(tvec, e1);
-                    const float v = dot(d, qvec) * inv_det;
-                    const float dist = dot(e2, qvec) * inv_det;
-                    // the reference's `continue` tests, negated one by one (NaN behaves the same)
-                    const bool keep = !(f_abs(determinant) < 1e-4f) && !(u < 0.0f || u > 1.0f) &&
-                                      !(v < 0.0f || (u + v) > 1.0f) && !(dist <= 0.0f);
-                    if (keep && dist < mt) {
-                        mt = dist;
-                        mid = (int32_t)k;
+                const f32x2 ox2 = splat2(o.x), oy2 = splat2(o.y), oz2 = splat2(o.z);
+                const f32x2 dx2 = splat2(d.x), dy2 = splat2(d.y), dz2 = splat2(d.z);
+                const uint32_t n_pairs = (ob.tri_count + 1u) >> 1;
+                for (uint32_t p = 0; p < n_pairs; ++p) {
+                    const TriPairRec tr = S.tri_pairs[ob.pair_begin + p];  // wave-uniform -> scalar loads
+                    const f32x2 e1x = ld2(tr.e1x), e1y = ld2(tr.e1y), e1z = ld2(tr.e1z);
+                    const f32x2 e2x = ld2(tr.e2x), e2y = ld2(tr.e2y), e2z = ld2(tr.e2z);
+                    // pvec = ray.direction.cross(va_vc)                          (mod.rs:563)
+                    const f32x2 px = dy2 * e2z - e2y * dz2, py = dz2 * e2x - e2z * dx2, pz = dx2 * e2y - e2x * dy2;
+                    const f32x2 determinant = (e1x * px + e1y * py) + e1z * pz;  // mod.rs:564
+                    const f32x2 inv_det = 1.0f / determinant;                    // mod.rs:576
+                    const f32x2 tx = ox2 - ld2(tr.ax), ty = oy2 - ld2(tr.ay), tz = oz2 - ld2(tr.az);  // mod.rs:577
+                    const f32x2 u = ((tx * px + ty * py) + tz * pz) * inv_det;                        // mod.rs:578
+                    // qvec = tvec.cross(va_vb)                                   (mod.rs:583)
+                    const f32x2 qx = ty * e1z - e1y * tz, qy = tz * e1x - e1z * tx, qz = tx * e1y - e1x * ty;
+                    const f32x2 v = ((dx2 * qx + dy2 * qy) + dz2 * qz) * inv_det;     // mod.rs:584
+                    const f32x2 dist = ((e2x * qx + e2y * qy) + e2z * qz) * inv_det;  // mod.rs:589
+                    const f32x2 uv = u + v;
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {  // list order: the earlier triangle keeps ties (mod.rs:598)
+                        // the reference's `continue` tests, negated one by one (NaN behaves the same)
+                        const bool keep = !(f_abs(determinant[hf]) < 1e-4f) && !(u[hf] < 0.0f || u[hf] > 1.0f) &&
+                                          !(v[hf] < 0.0f || uv[hf] > 1.0f) && !(dist[hf] <= 0.0f);
+                        if (keep && dist[hf] < mt) {
+                            mt = dist[hf];
+                            mid = (int32_t)(ob.tri_begin + 2u * p) + hf;
+                        }
                     }
                 }
                 if (sph_hit && mid >= 0 && mt < best_t) {

@@ -57,7 +57,7 @@ bool flatten_scene(const pt_object *objs, uint32_t n_objs, const pt_triangle *tr
     }
     out.objs.assign(n_objs, ObjRec{});
     out.mats.assign(n_objs, MatRec{});
-    out.tris.assign(n_tris, TriRec{});
+    out.tri_pairs.clear();
     out.tri_shade.assign(n_tris, TriShade{});
     std::vector<uint8_t> claimed(n_tris, 0);
     for (uint32_t i = 0; i < n_objs; ++i) {
@@ -81,6 +81,7 @@ bool flatten_scene(const pt_object *objs, uint32_t n_objs, const pt_triangle *tr
             r.rr = o.radius * o.radius;  // radius.powi(2), mod.rs:416
             r.tri_begin = 0;
             r.tri_count = 0;
+            r.pair_begin = 0;
         } else {
             if ((uint64_t)o.tri_offset + o.tri_count > n_tris) {
                 err = "object " + std::to_string(i) + ": triangle range outside the triangle array";
@@ -93,6 +94,8 @@ bool flatten_scene(const pt_object *objs, uint32_t n_objs, const pt_triangle *tr
             r.rr = o.bs_radius * o.bs_radius;
             r.tri_begin = o.tri_offset;
             r.tri_count = o.tri_count;
+            r.pair_begin = (uint32_t)out.tri_pairs.size();
+            out.tri_pairs.resize(out.tri_pairs.size() + (o.tri_count + 1u) / 2u, TriPairRec{});
             for (uint32_t k = o.tri_offset; k < o.tri_offset + o.tri_count; ++k) {
                 if (claimed[k]) {
                     err = "triangle " + std::to_string(k) + " belongs to two objects";
@@ -103,16 +106,18 @@ bool flatten_scene(const pt_object *objs, uint32_t n_objs, const pt_triangle *tr
                 const vec3 b = ld(tris[k].b) + position;
                 const vec3 c = ld(tris[k].c) + position;
                 const vec3 e1 = b - a, e2 = c - a;  // mod.rs:560-561
-                TriRec &t = out.tris[k];
-                t.ax = a.x;
-                t.ay = a.y;
-                t.az = a.z;
-                t.e1x = e1.x;
-                t.e1y = e1.y;
-                t.e1z = e1.z;
-                t.e2x = e2.x;
-                t.e2y = e2.y;
-                t.e2z = e2.z;
+                const uint32_t local = k - o.tri_offset;
+                TriPairRec &t = out.tri_pairs[r.pair_begin + local / 2u];
+                const uint32_t hf = local & 1u;
+                t.ax[hf] = a.x;
+                t.ay[hf] = a.y;
+                t.az[hf] = a.z;
+                t.e1x[hf] = e1.x;
+                t.e1y[hf] = e1.y;
+                t.e1z[hf] = e1.z;
+                t.e2x[hf] = e2.x;
+                t.e2y[hf] = e2.y;
+                t.e2z[hf] = e2.z;
                 const vec3 nrm = normalize(cross(e1, e2));  // mod.rs:605
                 TriShade &s = out.tri_shade[k];
                 s.nx = nrm.x;
