@@ -66,6 +66,8 @@ struct pt_ctx {
     DevBuf<TriPairRec> d_tris;
     DevBuf<MatRec> d_mats;
     DevBuf<TriShade> d_tshade;
+    DevBuf<BvhNode> d_nodes;
+    uint32_t n_bvh_nodes = 0;
     // wavefront queues
     uint32_t K = 0, cap = 0;
     DevBuf<float4> q_od0[2], q_tp[2];
@@ -406,6 +408,7 @@ void pt_ctx_destroy(pt_ctx *c) {
     c->d_tris.release();
     c->d_mats.release();
     c->d_tshade.release();
+    c->d_nodes.release();
     for (int w = 0; w < 2; ++w) {
         c->q_od0[w].release();
         c->q_od1[w].release();
@@ -430,14 +433,15 @@ int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uin
     }
     host::FlatScene fs;
     std::string err;
-    if (!host::flatten_scene(objs, n_objs, tris, n_tris, fs, err)) {
+    if (!host::flatten_scene(*cam, objs, n_objs, tris, n_tris, fs, err)) {
         set_error(err);
         return PT_ERR_INVALID;
     }
     HIP_TRY(hipSetDevice(c->device));
     int rc;
     if ((rc = c->d_objs.ensure(fs.objs.size())) || (rc = c->d_tris.ensure(fs.tri_pairs.size())) ||
-        (rc = c->d_mats.ensure(fs.mats.size())) || (rc = c->d_tshade.ensure(fs.tri_shade.size())))
+        (rc = c->d_mats.ensure(fs.mats.size())) || (rc = c->d_tshade.ensure(fs.tri_shade.size())) ||
+        (rc = c->d_nodes.ensure(fs.bvh_nodes.size())))
         return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (!fs.objs.empty())
@@ -450,6 +454,14 @@ int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uin
     if (!fs.tri_shade.empty())
         HIP_TRY(hipMemcpy(c->d_tshade.p, fs.tri_shade.data(), fs.tri_shade.size() * sizeof(TriShade),
                           hipMemcpyHostToDevice));
+    if (!fs.bvh_nodes.empty())
+        HIP_TRY(hipMemcpy(c->d_nodes.p, fs.bvh_nodes.data(), fs.bvh_nodes.size() * sizeof(BvhNode),
+                          hipMemcpyHostToDevice));
+    c->n_bvh_nodes = (uint32_t)fs.bvh_nodes.size();
+    c->scene.bvh_nodes = c->d_nodes.p;
+    c->scene.n_bvh_nodes = c->n_bvh_nodes;
+    c->scene.bvh_in_lds = (c->n_bvh_nodes <= kBvhMaxLdsNodes && fs.bvh_pair_span < 0x8000u) ? 1u : 0u;
+    c->scene.bvh_pair_base = fs.bvh_pair_base;
     c->scene.objs = c->d_objs.p;
     c->scene.tri_pairs = c->d_tris.p;
     c->scene.mats = c->d_mats.p;
@@ -487,6 +499,8 @@ int pt_ctx_render(pt_ctx *c, const pt_config *cfg, void *d_out_rgb, void *hip_st
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     const FrameParams F = make_frame(c, cfg, ib, ie);
     if (stats) memset(stats, 0, sizeof *stats);
+    // PT_FLAG_NO_BVH: scan meshes triangle by triangle as the reference does (same result, for A/B checks)
+    c->scene.n_bvh_nodes = (cfg->flags & PT_FLAG_NO_BVH) ? 0u : c->n_bvh_nodes;
     const double t0 = now_ms();
     if (cfg->backend == PT_BACKEND_WAVEFRONT)
         rc = render_wavefront(c, cfg, F, st, cancel, cb, user, stats);
@@ -500,6 +514,7 @@ int pt_ctx_render(pt_ctx *c, const pt_config *cfg, void *d_out_rgb, void *hip_st
         if (cb && rc == PT_OK) cb(user, 1.0f);
     }
     if (stats) stats->ms_total = now_ms() - t0;
+    c->scene.n_bvh_nodes = c->n_bvh_nodes;
     return rc;
 }
 

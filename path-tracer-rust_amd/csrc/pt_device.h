@@ -32,7 +32,10 @@ struct alignas(16) ObjRec {
     uint32_t kind;       // kKindSphere / kKindMesh
     uint32_t tri_begin;   // first triangle of the mesh in the flattened triangle numbering
     uint32_t tri_count;
-    uint32_t pair_begin;  // first TriPairRec of the mesh; it has (tri_count+1)/2 of them
+    uint32_t pair_begin;  // first TriPairRec of the mesh
+    uint32_t pair_count;  // number of TriPairRec of the mesh (>= (tri_count+1)/2; BVH leaves may be half full)
+    int32_t bvh_root;     // kNoBvh, or the root reference of the mesh's BVH (>= 0 node index, < 0: ~pair index)
+    uint32_t pad0, pad1;
 };
 
 // Two consecutive triangles of one mesh (world space), component by component, read with a wave-uniform
@@ -47,8 +50,24 @@ struct alignas(16) TriPairRec {
     float ax[2], ay[2], az[2];     // tri.a + offset                            (mod.rs:548)
     float e1x[2], e1y[2], e1z[2];  // va_vb = (tri.b+offset) - (tri.a+offset)   (mod.rs:560)
     float e2x[2], e2y[2], e2z[2];  // va_vc                                      (mod.rs:561)
-    float pad[2];
+    uint32_t id[2];                // flattened triangle index of each half (kNoTri for a filler half)
 };
+
+// BVH over the triangles of one large mesh: a node stores the (padded) boxes of its two children, so one
+// 64-byte fetch decides both.  Child reference >= 0: node index; < 0: ~index of a TriPairRec leaf.
+// Nodes are staged in LDS by every workgroup (per-lane, divergent indexing); leaves stay in global memory.
+// The two boxes are stored component-interleaved so that both are tested by one packed instruction per step.
+struct alignas(16) BvhNode {
+    float lox[2], loy[2], loz[2];
+    float hix[2], hiy[2], hiz[2];
+    int32_t c[2];
+    uint32_t pad[2];
+};
+constexpr int32_t kNoBvh = 0x7fffffff;
+constexpr uint32_t kNoTri = 0x7fffffffu;
+constexpr uint32_t kBvhStack = 24;          // per-lane traversal stack entries (LDS; u16 each when nodes are staged)
+constexpr uint32_t kBvhMinTris = 16;        // meshes with fewer triangles are scanned linearly
+constexpr uint32_t kBvhMaxLdsNodes = 1024;  // 64 KiB of nodes at most are staged in LDS
 
 // per-object material record, gathered per lane in shade
 struct alignas(16) MatRec {
@@ -69,8 +88,12 @@ struct DevScene {
     const TriPairRec *tri_pairs;
     const MatRec *mats;
     const TriShade *tri_shade;
+    const BvhNode *bvh_nodes;
     uint32_t n_objs;
     uint32_t n_tris;
+    uint32_t n_bvh_nodes;  // 0: no mesh of the scene has a BVH (or BVH use is switched off for this frame)
+    uint32_t bvh_in_lds;   // nodes are staged in LDS (n_bvh_nodes <= kBvhMaxLdsNodes)
+    uint32_t bvh_pair_base;  // first TriPairRec that is a BVH leaf (leaf references on a u16 stack are relative to it)
 };
 
 // per-frame constants
@@ -113,10 +136,156 @@ __device__ __forceinline__ f32x2 ld2(const float (&p)[2]) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// One ray against the two triangles of a TriPairRec: Triangle::intersect's arithmetic (mod.rs:559-594), both
+// triangles per packed instruction.  Updates the mesh-local closest hit (mt, mid).
+//   ORDERED: records are visited in list order, so strict '<' keeps the first of equal distances (mod.rs:598);
+//   otherwise (BVH order) the tie is broken explicitly towards the smaller triangle index: same result.
+template <bool ORDERED>
+__device__ __forceinline__ void test_pair(const TriPairRec &tr, f32x2 ox2, f32x2 oy2, f32x2 oz2, f32x2 dx2, f32x2 dy2,
+                                          f32x2 dz2, float &mt, int32_t &mid) {
+    const f32x2 e1x = ld2(tr.e1x), e1y = ld2(tr.e1y), e1z = ld2(tr.e1z);
+    const f32x2 e2x = ld2(tr.e2x), e2y = ld2(tr.e2y), e2z = ld2(tr.e2z);
+    // pvec = ray.direction.cross(va_vc)                                       (mod.rs:563)
+    const f32x2 px = dy2 * e2z - e2y * dz2, py = dz2 * e2x - e2z * dx2, pz = dx2 * e2y - e2x * dy2;
+    const f32x2 determinant = (e1x * px + e1y * py) + e1z * pz;                // mod.rs:564
+    const f32x2 inv_det = 1.0f / determinant;                                  // mod.rs:576
+    const f32x2 tx = ox2 - ld2(tr.ax), ty = oy2 - ld2(tr.ay), tz = oz2 - ld2(tr.az);  // mod.rs:577
+    const f32x2 u = ((tx * px + ty * py) + tz * pz) * inv_det;                 // mod.rs:578
+    // qvec = tvec.cross(va_vb)                                                (mod.rs:583)
+    const f32x2 qx = ty * e1z - e1y * tz, qy = tz * e1x - e1z * tx, qz = tx * e1y - e1x * ty;
+    const f32x2 v = ((dx2 * qx + dy2 * qy) + dz2 * qz) * inv_det;              // mod.rs:584
+    const f32x2 dist = ((e2x * qx + e2y * qy) + e2z * qz) * inv_det;           // mod.rs:589
+    const f32x2 uv = u + v;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        // the reference's `continue` tests, negated one by one (NaN behaves the same)
+        const bool keep = !(f_abs(determinant[hf]) < 1e-4f) && !(u[hf] < 0.0f || u[hf] > 1.0f) &&
+                          !(v[hf] < 0.0f || uv[hf] > 1.0f) && !(dist[hf] <= 0.0f);
+        const int32_t id = (int32_t)tr.id[hf];
+        const bool closer = ORDERED ? (dist[hf] < mt) : (dist[hf] < mt || (dist[hf] == mt && id < mid));
+        if (keep && closer) {
+            mt = dist[hf];
+            mid = id;
+        }
+    }
+}
+
+// Slab test of the two (padded) child boxes of a node at once: packed fma/min/max, NaN-ignoring min/max (a
+// slab whose bounds come out NaN - ray parallel to it and 0*inf - simply does not constrain).  This test only
+// has to be conservative, not bit-identical to anything: the boxes are padded by the worst-case error of the
+// f32 Moller-Trumbore hit plus the roundoff of this test (pt_host.cpp), so a box reported as missed cannot hold
+// a triangle that the reference's arithmetic would accept closer than `bound`.
+__device__ __forceinline__ void hit_boxes(const BvhNode &n, f32x2 ivx, f32x2 ivy, f32x2 ivz, f32x2 oix, f32x2 oiy,
+                                          f32x2 oiz, float bound, bool *h0, bool *h1, f32x2 *t_in) {
+    const f32x2 ax = __builtin_elementwise_fma(ld2(n.lox), ivx, -oix), bx = __builtin_elementwise_fma(ld2(n.hix), ivx, -oix);
+    const f32x2 ay = __builtin_elementwise_fma(ld2(n.loy), ivy, -oiy), by = __builtin_elementwise_fma(ld2(n.hiy), ivy, -oiy);
+    const f32x2 az = __builtin_elementwise_fma(ld2(n.loz), ivz, -oiz), bz = __builtin_elementwise_fma(ld2(n.hiz), ivz, -oiz);
+    const f32x2 zero = splat2(0.0f);
+    const f32x2 tin = __builtin_elementwise_max(
+        __builtin_elementwise_max(__builtin_elementwise_min(ax, bx), __builtin_elementwise_min(ay, by)),
+        __builtin_elementwise_max(__builtin_elementwise_min(az, bz), zero));
+    const f32x2 tout = __builtin_elementwise_min(
+        __builtin_elementwise_min(__builtin_elementwise_max(ax, bx), __builtin_elementwise_max(ay, by)),
+        __builtin_elementwise_max(az, bz));
+    const f32x2 lim = tout * splat2(1.0000005f);
+    *h0 = tin[0] <= lim[0] && tin[0] <= bound;
+    *h1 = tin[1] <= lim[1] && tin[1] <= bound;
+    *t_in = tin;
+}
+
+// Traversal-stack entry codecs.  With the nodes staged in LDS the scene has < 2^15 nodes and BVH leaves, so a
+// child reference fits 16 bits (halves the LDS the stacks take, which is what bounds occupancy here).
+struct Stack16 {
+    typedef uint16_t T;
+    uint32_t pair_base;
+    __device__ __forceinline__ T enc(int32_t r) const {
+        return (T)(r >= 0 ? (uint32_t)r : (0x8000u | ((uint32_t)(~r) - pair_base)));
+    }
+    __device__ __forceinline__ int32_t dec(T e) const {
+        return (e & 0x8000u) ? ~(int32_t)((uint32_t)(e & 0x7fffu) + pair_base) : (int32_t)e;
+    }
+};
+struct Stack32 {
+    typedef uint32_t T;
+    __device__ __forceinline__ T enc(int32_t r) const { return (T)r; }
+    __device__ __forceinline__ int32_t dec(T e) const { return (int32_t)e; }
+};
+
+// Closest triangle of one BVH mesh for one lane.  `nodes` is LDS (staged) or global memory; `stack` is this
+// lane's column of the workgroup's LDS stack (stride `stride`).  Only triangles that could beat `best_t`
+// matter to the caller (mod.rs:649 replaces on strict '<'), so boxes farther than min(mt, best_t) are skipped.
+template <class NodePtr, class Codec>
+__device__ __forceinline__ void bvh_closest(const DevScene &S, NodePtr nodes, Codec codec, typename Codec::T *stack,
+                                            uint32_t stride, vec3 o, vec3 d, int32_t root, float best_t, float &mt,
+                                            int32_t &mid) {
+    // 1/d clamped to +-1e18: a direction component that is exactly 0 (diffuse draw r2 == 0 off an axis-aligned
+    // wall, mirror rays) must give finite slab bounds whose sign still says on which side of the origin the
+    // plane lies; with +-inf the fma form below would turn "inside the slab" into NaN/-inf.
+    const float big = 1e18f;
+    const vec3 inv = mk(__builtin_fmaxf(__builtin_fminf(1.0f / d.x, big), -big),
+                        __builtin_fmaxf(__builtin_fminf(1.0f / d.y, big), -big),
+                        __builtin_fmaxf(__builtin_fminf(1.0f / d.z, big), -big));
+    const f32x2 ivx = splat2(inv.x), ivy = splat2(inv.y), ivz = splat2(inv.z);
+    const f32x2 oix = splat2(o.x * inv.x), oiy = splat2(o.y * inv.y), oiz = splat2(o.z * inv.z);
+    const f32x2 ox2 = splat2(o.x), oy2 = splat2(o.y), oz2 = splat2(o.z);
+    const f32x2 dx2 = splat2(d.x), dy2 = splat2(d.y), dz2 = splat2(d.z);
+    constexpr int32_t kDone = (int32_t)0x80000000;  // not a valid leaf reference (~0x7fffffff)
+    uint32_t sp = 0;
+    int32_t cur = root;
+    for (;;) {
+        // 1. walk down through inner nodes until this lane stands on a leaf (or has nothing left).  Lanes that
+        //    arrive early wait here, so the (longer) triangle code below runs once per round for the whole wave.
+        while (cur >= 0) {
+            const BvhNode n = nodes[cur];
+            const float bound = __builtin_fminf(mt, best_t);
+            bool h0, h1;
+            f32x2 tin;
+            hit_boxes(n, ivx, ivy, ivz, oix, oiy, oiz, bound, &h0, &h1, &tin);
+            if (h0 && h1) {
+                const bool first0 = tin[0] <= tin[1];
+                if (sp < kBvhStack) stack[sp * stride] = codec.enc(first0 ? n.c[1] : n.c[0]);
+                ++sp;  // (the host guarantees tree depth < kBvhStack)
+                cur = first0 ? n.c[0] : n.c[1];
+            } else if (h0 || h1) {
+                cur = h0 ? n.c[0] : n.c[1];
+            } else if (sp != 0u) {
+                --sp;
+                cur = codec.dec(stack[sp * stride]);
+            } else {
+                cur = kDone;
+            }
+        }
+        if (cur == kDone) break;
+        // 2. leaf: two triangles
+        test_pair<false>(S.tri_pairs[~cur], ox2, oy2, oz2, dx2, dy2, dz2, mt, mid);
+        if (sp == 0u) break;
+        --sp;
+        cur = codec.dec(stack[sp * stride]);
+    }
+}
+
+// LDS carve-up of the kernels that intersect: [BvhNode x n_bvh_nodes][u16 stack: kBvhStack x blockDim] when the
+// nodes are staged, else [u32 stack: kBvhStack x blockDim] alone (nodes read from global memory)
+__device__ __forceinline__ void stage_bvh(const DevScene &S, uint4 *lds) {
+    if (S.n_bvh_nodes != 0u && S.bvh_in_lds != 0u) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(S.bvh_nodes);
+        for (uint32_t i = threadIdx.x; i < S.n_bvh_nodes * 4u; i += blockDim.x) lds[i] = src[i];
+        __syncthreads();
+    }
+}
+__host__ __device__ inline size_t bvh_lds_bytes(const DevScene &S, uint32_t block) {
+    if (S.n_bvh_nodes == 0u) return 0;
+    return S.bvh_in_lds ? (size_t)S.n_bvh_nodes * sizeof(BvhNode) + (size_t)kBvhStack * block * sizeof(uint16_t)
+                        : (size_t)kBvhStack * block * sizeof(uint32_t);
+}
+
+// ---------------------------------------------------------------------------------------------
 // closest hit.  Objects in reverse index order, strict '<' (ties keep the higher object index,
 // mod.rs:637,649); inside a mesh the first triangle in list order wins ties (mod.rs:598).
 // `best` starts at +inf instead of Option::None: identical for every finite, non-NaN distance.
-__device__ __forceinline__ HitRec intersect_scene_dev(const DevScene &S, vec3 o, vec3 d) {
+// BVH = false compiles the traversal out (scenes without a BVH mesh keep the small register footprint).
+template <bool BVH>
+__device__ __forceinline__ HitRec intersect_scene_dev(const DevScene &S, vec3 o, vec3 d, uint4 *lds) {
     float best_t = __builtin_inff();
     int32_t best_id = -1;
     const float eps = 1e-4f;
@@ -140,33 +309,28 @@ __device__ __forceinline__ HitRec intersect_scene_dev(const DevScene &S, vec3 o,
             if (__builtin_amdgcn_ballot_w64(sph_hit) != 0ull) {
                 float mt = __builtin_inff();
                 int32_t mid = -1;
-                const f32x2 ox2 = splat2(o.x), oy2 = splat2(o.y), oz2 = splat2(o.z);
-                const f32x2 dx2 = splat2(d.x), dy2 = splat2(d.y), dz2 = splat2(d.z);
-                const uint32_t n_pairs = (ob.tri_count + 1u) >> 1;
-                for (uint32_t p = 0; p < n_pairs; ++p) {
-                    const TriPairRec tr = S.tri_pairs[ob.pair_begin + p];  // wave-uniform -> scalar loads
-                    const f32x2 e1x = ld2(tr.e1x), e1y = ld2(tr.e1y), e1z = ld2(tr.e1z);
-                    const f32x2 e2x = ld2(tr.e2x), e2y = ld2(tr.e2y), e2z = ld2(tr.e2z);
-                    // pvec = ray.direction.cross(va_vc)                          (mod.rs:563)
-                    const f32x2 px = dy2 * e2z - e2y * dz2, py = dz2 * e2x - e2z * dx2, pz = dx2 * e2y - e2x * dy2;
-                    const f32x2 determinant = (e1x * px + e1y * py) + e1z * pz;  // mod.rs:564
-                    const f32x2 inv_det = 1.0f / determinant;                    // mod.rs:576
-                    const f32x2 tx = ox2 - ld2(tr.ax), ty = oy2 - ld2(tr.ay), tz = oz2 - ld2(tr.az);  // mod.rs:577
-                    const f32x2 u = ((tx * px + ty * py) + tz * pz) * inv_det;                        // mod.rs:578
-                    // qvec = tvec.cross(va_vb)                                   (mod.rs:583)
-                    const f32x2 qx = ty * e1z - e1y * tz, qy = tz * e1x - e1z * tx, qz = tx * e1y - e1x * ty;
-                    const f32x2 v = ((dx2 * qx + dy2 * qy) + dz2 * qz) * inv_det;     // mod.rs:584
-                    const f32x2 dist = ((e2x * qx + e2y * qy) + e2z * qz) * inv_det;  // mod.rs:589
-                    const f32x2 uv = u + v;
-#pragma unroll
-                    for (int hf = 0; hf < 2; ++hf) {  // list order: the earlier triangle keeps ties (mod.rs:598)
-                        // the reference's `continue` tests, negated one by one (NaN behaves the same)
-                        const bool keep = !(f_abs(determinant[hf]) < 1e-4f) && !(u[hf] < 0.0f || u[hf] > 1.0f) &&
-                                          !(v[hf] < 0.0f || uv[hf] > 1.0f) && !(dist[hf] <= 0.0f);
-                        if (keep && dist[hf] < mt) {
-                            mt = dist[hf];
-                            mid = (int32_t)(ob.tri_begin + 2u * p) + hf;
+                if (BVH && ob.bvh_root != kNoBvh && S.n_bvh_nodes != 0u) {
+                    if (sph_hit) {  // per lane: divergent traversal
+                        if (S.bvh_in_lds) {
+                            uint16_t *stack = reinterpret_cast<uint16_t *>(lds + S.n_bvh_nodes * 4u) + threadIdx.x;
+                            Stack16 codec;
+                            codec.pair_base = S.bvh_pair_base;
+                            bvh_closest(S, reinterpret_cast<const BvhNode *>(lds), codec, stack, blockDim.x, o, d,
+                                        ob.bvh_root, best_t, mt, mid);
+                        } else {
+                            uint32_t *stack = reinterpret_cast<uint32_t *>(lds) + threadIdx.x;
+                            bvh_closest(S, S.bvh_nodes, Stack32(), stack, blockDim.x, o, d, ob.bvh_root, best_t, mt, mid);
                         }
+                    }
+                } else {
+                    const f32x2 ox2 = splat2(o.x), oy2 = splat2(o.y), oz2 = splat2(o.z);
+                    const f32x2 dx2 = splat2(d.x), dy2 = splat2(d.y), dz2 = splat2(d.z);
+                    if (ob.bvh_root == kNoBvh) {
+                        for (uint32_t p = 0; p < ob.pair_count; ++p)  // wave-uniform index -> scalar loads
+                            test_pair<true>(S.tri_pairs[ob.pair_begin + p], ox2, oy2, oz2, dx2, dy2, dz2, mt, mid);
+                    } else {  // BVH switched off for this frame: the reference's full scan over BVH-ordered records
+                        for (uint32_t p = 0; p < ob.pair_count; ++p)
+                            test_pair<false>(S.tri_pairs[ob.pair_begin + p], ox2, oy2, oz2, dx2, dy2, dz2, mt, mid);
                     }
                 }
                 if (sph_hit && mid >= 0 && mt < best_t) {

@@ -3,6 +3,7 @@
 // for the triangle edges — see pt_device.h).
 #include "pt_host.h"
 
+#include <algorithm>
 #include <cmath>
 #include <limits>
 
@@ -49,8 +50,126 @@ void mesh_bounding_sphere(const pt_triangle *tris, uint32_t n, float center[3], 
     *radius = to_lo > to_hi ? to_lo : to_hi;  // max_by keeps the last of equal maxima
 }
 
-bool flatten_scene(const pt_object *objs, uint32_t n_objs, const pt_triangle *tris, uint32_t n_tris, FlatScene &out,
-                   std::string &err) {
+namespace {
+
+struct BuildTri {
+    vec3 lo, hi, mid;
+    vec3 a, e1, e2;
+    uint32_t id;  // flattened triangle index
+};
+
+struct BvhBuilder {
+    FlatScene &out;
+    std::vector<BuildTri> &t;  // lo/hi already padded per triangle
+    bool use_sah = true;       // false: median split (balanced: depth <= log2(n) + 1)
+    uint32_t depth_max = 0;
+
+    static void grow(vec3 &lo, vec3 &hi, const vec3 &l, const vec3 &h) {
+        lo = mk(std::fmin(lo.x, l.x), std::fmin(lo.y, l.y), std::fmin(lo.z, l.z));
+        hi = mk(std::fmax(hi.x, h.x), std::fmax(hi.y, h.y), std::fmax(hi.z, h.z));
+    }
+
+    // returns the child reference of the subtree over t[b,e) and its padded box
+    int32_t build(size_t b, size_t e, vec3 &lo, vec3 &hi, uint32_t depth) {
+        const float inf = std::numeric_limits<float>::infinity();
+        lo = mk(inf, inf, inf);
+        hi = mk(-inf, -inf, -inf);
+        depth_max = depth > depth_max ? depth : depth_max;
+        if (e - b <= 2) {  // leaf = one TriPairRec
+            TriPairRec rec{};
+            rec.id[0] = rec.id[1] = kNoTri;  // a filler half is all zeros: determinant 0, rejected (mod.rs:571)
+            for (size_t k = b; k < e; ++k) {
+                const uint32_t hf = (uint32_t)(k - b);
+                const BuildTri &q = t[k];
+                rec.ax[hf] = q.a.x, rec.ay[hf] = q.a.y, rec.az[hf] = q.a.z;
+                rec.e1x[hf] = q.e1.x, rec.e1y[hf] = q.e1.y, rec.e1z[hf] = q.e1.z;
+                rec.e2x[hf] = q.e2.x, rec.e2y[hf] = q.e2.y, rec.e2z[hf] = q.e2.z;
+                rec.id[hf] = q.id;
+                grow(lo, hi, q.lo, q.hi);
+            }
+            out.tri_pairs.push_back(rec);
+            return ~(int32_t)(out.tri_pairs.size() - 1);
+        }
+        // surface-area-heuristic split: for each axis sort by centroid and sweep; only even left counts are
+        // considered so that leaves are full pairs wherever possible.  Ties are broken by triangle id: the tree
+        // (and with it the traversal order) is a pure function of the scene.
+        const size_t cnt = e - b;
+        size_t half = 0;
+        int best_axis = -1;
+        float best_cost = inf;
+        std::vector<float> right_area(cnt + 1);
+        auto area = [](const vec3 &l, const vec3 &h) {
+            const vec3 d = h - l;
+            return 2.0f * (d.x * d.y + d.y * d.z + d.z * d.x);
+        };
+        for (int axis = 0; use_sah && axis < 3; ++axis) {
+            auto key = [axis](const BuildTri &q) { return axis == 0 ? q.mid.x : (axis == 1 ? q.mid.y : q.mid.z); };
+            std::sort(t.begin() + (long)b, t.begin() + (long)e, [&](const BuildTri &x, const BuildTri &y) {
+                const float kx = key(x), ky = key(y);
+                return kx < ky || (kx == ky && x.id < y.id);
+            });
+            vec3 l = mk(inf, inf, inf), h = mk(-inf, -inf, -inf);
+            for (size_t k = cnt; k-- > 0;) {
+                grow(l, h, t[b + k].lo, t[b + k].hi);
+                right_area[k] = area(l, h);
+            }
+            l = mk(inf, inf, inf), h = mk(-inf, -inf, -inf);
+            for (size_t k = 1; k < cnt; ++k) {
+                grow(l, h, t[b + k - 1].lo, t[b + k - 1].hi);
+                if (k & 1) continue;
+                const float cost = area(l, h) * (float)k + right_area[k] * (float)(cnt - k);
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best_axis = axis;
+                    half = k;
+                }
+            }
+        }
+        if (best_axis < 0 && use_sah) {  // cnt == 3: one full pair + one half-filled leaf
+            best_axis = 2;
+            half = 2;
+        }
+        if (!use_sah) {  // median of the widest centroid axis, left count even
+            vec3 clo = mk(inf, inf, inf), chi = mk(-inf, -inf, -inf);
+            for (size_t k = b; k < e; ++k) grow(clo, chi, t[k].mid, t[k].mid);
+            const vec3 ext = chi - clo;
+            best_axis = (ext.x >= ext.y && ext.x >= ext.z) ? 0 : (ext.y >= ext.z ? 1 : 2);
+            half = ((cnt / 2) + 1) & ~(size_t)1;
+            if (half >= cnt) half = 2;
+            const int axis = best_axis;
+            auto key = [axis](const BuildTri &q) { return axis == 0 ? q.mid.x : (axis == 1 ? q.mid.y : q.mid.z); };
+            std::sort(t.begin() + (long)b, t.begin() + (long)e, [&](const BuildTri &x, const BuildTri &y) {
+                const float kx = key(x), ky = key(y);
+                return kx < ky || (kx == ky && x.id < y.id);
+            });
+        } else if (best_axis != 2) {  // the array is currently sorted along z: restore the winning order
+            const int axis = best_axis;
+            auto key = [axis](const BuildTri &q) { return axis == 0 ? q.mid.x : q.mid.y; };
+            std::sort(t.begin() + (long)b, t.begin() + (long)e, [&](const BuildTri &x, const BuildTri &y) {
+                const float kx = key(x), ky = key(y);
+                return kx < ky || (kx == ky && x.id < y.id);
+            });
+        }
+        const size_t node_at = out.bvh_nodes.size();
+        out.bvh_nodes.push_back(BvhNode{});
+        vec3 l0, h0, l1, h1;
+        const int32_t c0 = build(b, b + half, l0, h0, depth + 1);
+        const int32_t c1 = build(b + half, e, l1, h1, depth + 1);
+        BvhNode &n = out.bvh_nodes[node_at];
+        n.lox[0] = l0.x, n.loy[0] = l0.y, n.loz[0] = l0.z, n.hix[0] = h0.x, n.hiy[0] = h0.y, n.hiz[0] = h0.z;
+        n.lox[1] = l1.x, n.loy[1] = l1.y, n.loz[1] = l1.z, n.hix[1] = h1.x, n.hiy[1] = h1.y, n.hiz[1] = h1.z;
+        n.c[0] = c0;
+        n.c[1] = c1;
+        grow(lo, hi, l0, h0);
+        grow(lo, hi, l1, h1);
+        return (int32_t)node_at;
+    }
+};
+
+}  // namespace
+
+bool flatten_scene(const pt_camera &cam, const pt_object *objs, uint32_t n_objs, const pt_triangle *tris,
+                   uint32_t n_tris, FlatScene &out, std::string &err) {
     if (n_objs >= (1u << 30) || n_tris >= (1u << 30)) {
         err = "scene too large";
         return false;
@@ -58,8 +177,34 @@ bool flatten_scene(const pt_object *objs, uint32_t n_objs, const pt_triangle *tr
     out.objs.assign(n_objs, ObjRec{});
     out.mats.assign(n_objs, MatRec{});
     out.tri_pairs.clear();
+    out.bvh_nodes.clear();
     out.tri_shade.assign(n_tris, TriShade{});
+    // R: bound on |ray origin - any vertex|: ray origins are the lens centre or points on objects
+    const float finf = std::numeric_limits<float>::infinity();
+    vec3 slo = mk(finf, finf, finf), shi = mk(-finf, -finf, -finf);
+    {
+        float lens[3], su[3], sv[3];
+        camera_basis(cam, lens, su, sv);
+        BvhBuilder::grow(slo, shi, ld(lens), ld(lens));
+        for (uint32_t i = 0; i < n_objs; ++i) {
+            const vec3 pos = ld(objs[i].position);
+            if (objs[i].kind == PT_SPHERE) {
+                const float r = f_abs(objs[i].radius);
+                BvhBuilder::grow(slo, shi, pos - mk(r, r, r), pos + mk(r, r, r));
+            } else if (objs[i].kind == PT_MESH && (uint64_t)objs[i].tri_offset + objs[i].tri_count <= n_tris) {
+                for (uint32_t k = objs[i].tri_offset; k < objs[i].tri_offset + objs[i].tri_count; ++k) {
+                    BvhBuilder::grow(slo, shi, ld(tris[k].a) + pos, ld(tris[k].a) + pos);
+                    BvhBuilder::grow(slo, shi, ld(tris[k].b) + pos, ld(tris[k].b) + pos);
+                    BvhBuilder::grow(slo, shi, ld(tris[k].c) + pos, ld(tris[k].c) + pos);
+                }
+            }
+        }
+    }
+    const float scene_R = n_objs ? length(shi - slo) : 0.0f;
     std::vector<uint8_t> claimed(n_tris, 0);
+    bool have_bvh = false;
+    out.bvh_pair_base = 0;
+    out.bvh_pair_span = 0;
     for (uint32_t i = 0; i < n_objs; ++i) {
         const pt_object &o = objs[i];
         if (o.kind != PT_SPHERE && o.kind != PT_MESH) {
@@ -82,6 +227,8 @@ bool flatten_scene(const pt_object *objs, uint32_t n_objs, const pt_triangle *tr
             r.tri_begin = 0;
             r.tri_count = 0;
             r.pair_begin = 0;
+            r.pair_count = 0;
+            r.bvh_root = kNoBvh;
         } else {
             if ((uint64_t)o.tri_offset + o.tri_count > n_tris) {
                 err = "object " + std::to_string(i) + ": triangle range outside the triangle array";
@@ -95,7 +242,9 @@ bool flatten_scene(const pt_object *objs, uint32_t n_objs, const pt_triangle *tr
             r.tri_begin = o.tri_offset;
             r.tri_count = o.tri_count;
             r.pair_begin = (uint32_t)out.tri_pairs.size();
-            out.tri_pairs.resize(out.tri_pairs.size() + (o.tri_count + 1u) / 2u, TriPairRec{});
+            r.bvh_root = kNoBvh;
+            std::vector<BuildTri> bt;
+            bt.reserve(o.tri_count);
             for (uint32_t k = o.tri_offset; k < o.tri_offset + o.tri_count; ++k) {
                 if (claimed[k]) {
                     err = "triangle " + std::to_string(k) + " belongs to two objects";
@@ -106,25 +255,69 @@ bool flatten_scene(const pt_object *objs, uint32_t n_objs, const pt_triangle *tr
                 const vec3 b = ld(tris[k].b) + position;
                 const vec3 c = ld(tris[k].c) + position;
                 const vec3 e1 = b - a, e2 = c - a;  // mod.rs:560-561
-                const uint32_t local = k - o.tri_offset;
-                TriPairRec &t = out.tri_pairs[r.pair_begin + local / 2u];
-                const uint32_t hf = local & 1u;
-                t.ax[hf] = a.x;
-                t.ay[hf] = a.y;
-                t.az[hf] = a.z;
-                t.e1x[hf] = e1.x;
-                t.e1y[hf] = e1.y;
-                t.e1z[hf] = e1.z;
-                t.e2x[hf] = e2.x;
-                t.e2y[hf] = e2.y;
-                t.e2z[hf] = e2.z;
                 const vec3 nrm = normalize(cross(e1, e2));  // mod.rs:605
                 TriShade &s = out.tri_shade[k];
                 s.nx = nrm.x;
                 s.ny = nrm.y;
                 s.nz = nrm.z;
                 s.owner = i;
+                BuildTri q;
+                q.a = a, q.e1 = e1, q.e2 = e2, q.id = k;
+                q.lo = mk(std::fmin(a.x, std::fmin(b.x, c.x)), std::fmin(a.y, std::fmin(b.y, c.y)),
+                          std::fmin(a.z, std::fmin(b.z, c.z)));
+                q.hi = mk(std::fmax(a.x, std::fmax(b.x, c.x)), std::fmax(a.y, std::fmax(b.y, c.y)),
+                          std::fmax(a.z, std::fmax(b.z, c.z)));
+                q.mid = (q.lo + q.hi) * 0.5f;
+                {
+                    // Padding = bound on how far from the exact triangle a hit accepted by the f32 Moller-Trumbore
+                    // arithmetic can lie.  With |det| >= 1e-4 (mod.rs:571), |tvec| <= R (scene diagonal), this
+                    // triangle's edges <= L and unit roundoff e = 2^-24, forward error analysis of mod.rs:560-589
+                    // gives |du|,|dv| <= e L (7L + 8R) / 1e-4 (the hit point moves by that times L) and
+                    // |dt| <= e L^2 (7 t + 8R) / 1e-4 with t <= R; 16 e L^2 (R+L) / 1e-4 covers each of the three,
+                    // so three times that (the 16 already holds a factor 2 of slack), plus the slab test's own roundoff.
+                    const float L = std::fmax(length(e1), std::fmax(length(e2), length(c - b)));
+                    const float e = 5.9604645e-8f;
+                    const float pad = 3.0f * (16.0f * e * L * L * (scene_R + L) / 1e-4f) + 16.0f * e * (scene_R + L) + 1e-6f;
+                    q.lo = q.lo - mk(pad, pad, pad);
+                    q.hi = q.hi + mk(pad, pad, pad);
+                }
+                bt.push_back(q);
             }
+            if (o.tri_count >= kBvhMinTris) {
+                const size_t pairs_mark = out.tri_pairs.size(), nodes_mark = out.bvh_nodes.size();
+                const std::vector<BuildTri> keep = bt;
+                for (int attempt = 0; attempt < 2; ++attempt) {
+                    BvhBuilder bb{out, bt};
+                    bb.use_sah = attempt == 0;
+                    vec3 blo, bhi;
+                    r.bvh_root = bb.build(0, bt.size(), blo, bhi, 0);
+                    if (bb.depth_max + 2 < kBvhStack) break;
+                    if (attempt == 1) {
+                        err = "object " + std::to_string(i) + ": BVH deeper than the traversal stack";
+                        return false;
+                    }
+                    out.tri_pairs.resize(pairs_mark);  // SAH tree too deep for the stack: rebuild balanced
+                    out.bvh_nodes.resize(nodes_mark);
+                    bt = keep;
+                }
+                if (!have_bvh) out.bvh_pair_base = (uint32_t)pairs_mark;
+                have_bvh = true;
+                out.bvh_pair_span = (uint32_t)out.tri_pairs.size() - out.bvh_pair_base;
+            } else {
+                for (size_t k = 0; k < bt.size(); k += 2) {  // list order, two triangles per record
+                    TriPairRec rec{};
+                    rec.id[0] = rec.id[1] = kNoTri;
+                    for (size_t hf = 0; hf < 2 && k + hf < bt.size(); ++hf) {
+                        const BuildTri &q = bt[k + hf];
+                        rec.ax[hf] = q.a.x, rec.ay[hf] = q.a.y, rec.az[hf] = q.a.z;
+                        rec.e1x[hf] = q.e1.x, rec.e1y[hf] = q.e1.y, rec.e1z[hf] = q.e1.z;
+                        rec.e2x[hf] = q.e2.x, rec.e2y[hf] = q.e2.y, rec.e2z[hf] = q.e2.z;
+                        rec.id[hf] = q.id;
+                    }
+                    out.tri_pairs.push_back(rec);
+                }
+            }
+            r.pair_count = (uint32_t)out.tri_pairs.size() - r.pair_begin;
         }
         m.cr = o.color[0];
         m.cg = o.color[1];

@@ -18,6 +18,9 @@ struct FlatScene {
     std::vector<TriPairRec> tri_pairs;
     std::vector<MatRec> mats;
     std::vector<TriShade> tri_shade;
+    std::vector<BvhNode> bvh_nodes;
+    uint32_t bvh_pair_base = 0;  // first TriPairRec that is a BVH leaf
+    uint32_t bvh_pair_span = 0;  // leaves lie in [bvh_pair_base, bvh_pair_base + bvh_pair_span)
 };
 
 // CameraData::{lens_center, orthogonals} — src/render/mod.rs:211-232
@@ -25,8 +28,9 @@ void camera_basis(const pt_camera &cam, float lens_center[3], float su[3], float
 // Mesh::new bounding sphere — src/render/mod.rs:450-499
 void mesh_bounding_sphere(const pt_triangle *tris, uint32_t n, float center[3], float *radius);
 // validate + flatten (see pt_device.h for the record layouts); false + message on malformed input
-bool flatten_scene(const pt_object *objs, uint32_t n_objs, const pt_triangle *tris, uint32_t n_tris, FlatScene &out,
-                   std::string &err);
+// `cam` only widens the distance bound that sizes the BVH box padding (ray origins include the lens centre)
+bool flatten_scene(const pt_camera &cam, const pt_object *objs, uint32_t n_objs, const pt_triangle *tris,
+                   uint32_t n_tris, FlatScene &out, std::string &err);
 
 }  // namespace host
 }  // namespace pt

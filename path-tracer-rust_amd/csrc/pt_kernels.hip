@@ -23,6 +23,10 @@
 
 namespace pt {
 
+// dynamic LDS of the kernels that intersect: staged BVH nodes + per-lane traversal stacks (0 bytes for scenes
+// without a BVH mesh).  No static __shared__ object precedes it in those kernels, so its base is 16-byte aligned.
+extern __shared__ uint4 dyn_lds[];
+
 __device__ __forceinline__ uint32_t lane_prefix(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
@@ -58,16 +62,18 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams F, RayQueue q, 
 }
 
 // ------------------------------------------------------------------------------------------------
+template <bool BVH>
 __global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, RayQueue q, float2 *__restrict__ hit,
                                                       const uint32_t *__restrict__ cnt, uint32_t cap,
                                                       unsigned long long *__restrict__ blk_rays) {
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
     const uint32_t n = cnt[b];
     const size_t base = (size_t)b * cap;
+    if (BVH && n != 0u) stage_bvh(S, dyn_lds);
     for (uint32_t i = tid; i < n; i += kBlock) {
         const float4 a = q.od0[base + i];
         const float2 c = q.od1[base + i];
-        const HitRec h = intersect_scene_dev(S, mk(a.x, a.y, a.z), mk(a.w, c.x, c.y));
+        const HitRec h = intersect_scene_dev<BVH>(S, mk(a.x, a.y, a.z), mk(a.w, c.x, c.y), dyn_lds);
         hit[base + i] = make_float2(h.t, __int_as_float(h.id));
     }
     if (tid == 0) blk_rays[b] += n;
@@ -166,11 +172,13 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const unsigned long long *__
 // other and each loop trip advances every live path of the wave by one bounce, so the intersect and
 // shade code is executed by (nearly) full waves whatever the depths of the individual paths.
 // The refract split (mod.rs:775-786) pushes the transmitted ray on a two-entry stack in registers.
+template <bool BVH>
 __global__ __launch_bounds__(kBlock) void k_mega(DevScene S, FrameParams F, unsigned long long *__restrict__ acc,
                                                  uint32_t chunk_spp, uint32_t n_chunks,
                                                  unsigned long long *__restrict__ total_rays) {
     const uint64_t items = (uint64_t)F.npix * n_chunks;
     unsigned long long rays = 0;
+    if (BVH) stage_bvh(S, dyn_lds);
     for (uint64_t first = (uint64_t)blockIdx.x * kBlock; first < items; first += (uint64_t)gridDim.x * kBlock) {
         const uint64_t item = first + threadIdx.x;
         const bool lane_valid = item < items;
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(kBlock) void k_mega(DevScene S, FrameParams F, unsi
             }
             if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
             if (active) {
-                const HitRec h = intersect_scene_dev(S, cur.o, cur.d);
+                const HitRec h = intersect_scene_dev<BVH>(S, cur.o, cur.d, dyn_lds);
                 ++rays;
                 if (h.id < 0) {
                     active = false;
@@ -257,10 +265,11 @@ __global__ __launch_bounds__(kBlock) void k_query(DevScene S, const float *__res
                                                   const float *__restrict__ d, uint32_t n, float *__restrict__ t,
                                                   int32_t *__restrict__ object_id, int32_t *__restrict__ tri_id,
                                                   float *__restrict__ x, float *__restrict__ nrm) {
+    stage_bvh(S, dyn_lds);
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const vec3 ro = mk(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
         const vec3 rd = mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
-        const HitRec h = intersect_scene_dev(S, ro, rd);
+        const HitRec h = intersect_scene_dev<true>(S, ro, rd, dyn_lds);
         int32_t oid = -1, tid = -1;
         vec3 hx = mk(0.0f, 0.0f, 0.0f), hn = hx;
         float ht = 0.0f;
@@ -317,7 +326,11 @@ void launch_generate(hipStream_t st, uint32_t K, const FrameParams &F, const Ray
 }
 void launch_intersect(hipStream_t st, uint32_t K, const DevScene &S, const RayQueue &q, float2 *hit,
                       const uint32_t *cnt, uint32_t cap, unsigned long long *blk_rays) {
-    hipLaunchKernelGGL(k_intersect, dim3(K), dim3(kBlock), 0, st, S, q, hit, cnt, cap, blk_rays);
+    if (S.n_bvh_nodes != 0u)
+        hipLaunchKernelGGL(k_intersect<true>, dim3(K), dim3(kBlock), bvh_lds_bytes(S, kBlock), st, S, q, hit, cnt, cap,
+                           blk_rays);
+    else
+        hipLaunchKernelGGL(k_intersect<false>, dim3(K), dim3(kBlock), 0, st, S, q, hit, cnt, cap, blk_rays);
 }
 void launch_shade(hipStream_t st, uint32_t K, const DevScene &S, const FrameParams &F, const RayQueue &qin,
                   const RayQueue &qout, const float2 *hit, const uint32_t *cnt_in, uint32_t *cnt_out, uint32_t cap,
@@ -330,14 +343,18 @@ void launch_resolve(hipStream_t st, const unsigned long long *acc, float *out, u
 }
 void launch_mega(hipStream_t st, uint32_t grid, const DevScene &S, const FrameParams &F, unsigned long long *acc,
                  uint32_t chunk_spp, uint32_t n_chunks, unsigned long long *total_rays) {
-    hipLaunchKernelGGL(k_mega, dim3(grid), dim3(kBlock), 0, st, S, F, acc, chunk_spp, n_chunks, total_rays);
+    if (S.n_bvh_nodes != 0u)
+        hipLaunchKernelGGL(k_mega<true>, dim3(grid), dim3(kBlock), bvh_lds_bytes(S, kBlock), st, S, F, acc, chunk_spp,
+                           n_chunks, total_rays);
+    else
+        hipLaunchKernelGGL(k_mega<false>, dim3(grid), dim3(kBlock), 0, st, S, F, acc, chunk_spp, n_chunks, total_rays);
 }
 void launch_query(hipStream_t st, const DevScene &S, const float *o, const float *d, uint32_t n, float *t,
                   int32_t *object_id, int32_t *tri_id, float *x, float *nrm) {
     uint32_t grid = (n + kBlock - 1) / kBlock;
     if (grid > 4096u) grid = 4096u;
     if (grid == 0u) grid = 1u;
-    hipLaunchKernelGGL(k_query, dim3(grid), dim3(kBlock), 0, st, S, o, d, n, t, object_id, tri_id, x, nrm);
+    hipLaunchKernelGGL(k_query, dim3(grid), dim3(kBlock), bvh_lds_bytes(S, kBlock), st, S, o, d, n, t, object_id, tri_id, x, nrm);
 }
 void launch_numerics(hipStream_t st, const float *in, uint32_t n, float *out_sin, float *out_cos, float *out_sqrt,
                      float *out_rcp, uint32_t *out_philox) {
