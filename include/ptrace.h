@@ -154,6 +154,9 @@ int pt_ctx_intersect(pt_ctx *ctx, const float *o, const float *d, uint32_t n, fl
 int pt_ctx_numerics_probe(pt_ctx *ctx, const float *in, uint32_t n, float *out_sin, float *out_cos,
                           float *out_sqrt, float *out_rcp, uint32_t *out_philox);
 
+/* The host instantiation of the shared numerics header's sincos (the same source the kernels compile). */
+void pt_host_sincos(float y, float *s, float *c);
+
 /* The drop-in for mod.rs:1017-1024: host buffers in, host framebuffer out (whole W*H*3 floats,
  * only the band is written).  Uses device 0 (or PT_DEVICE env).  Blocking. */
 int pt_render(const pt_config *cfg, const pt_camera *cam, const pt_object *objs, uint32_t n_objs,

@@ -63,6 +63,7 @@ struct pt_ctx {
     pt_camera cam{};
     DevScene scene{};
     DevBuf<ObjRec> d_objs;
+    DevBuf<ObjPairRec> d_opairs;
     DevBuf<TriPairRec> d_tris;
     DevBuf<MatRec> d_mats;
     DevBuf<TriShade> d_tshade;
@@ -405,6 +406,7 @@ void pt_ctx_destroy(pt_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     c->d_objs.release();
+    c->d_opairs.release();
     c->d_tris.release();
     c->d_mats.release();
     c->d_tshade.release();
@@ -439,13 +441,16 @@ int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uin
     }
     HIP_TRY(hipSetDevice(c->device));
     int rc;
-    if ((rc = c->d_objs.ensure(fs.objs.size())) || (rc = c->d_tris.ensure(fs.tri_pairs.size())) ||
+    if ((rc = c->d_objs.ensure(fs.objs.size())) || (rc = c->d_opairs.ensure(fs.obj_pairs.size())) || (rc = c->d_tris.ensure(fs.tri_pairs.size())) ||
         (rc = c->d_mats.ensure(fs.mats.size())) || (rc = c->d_tshade.ensure(fs.tri_shade.size())) ||
         (rc = c->d_nodes.ensure(fs.bvh_nodes.size())))
         return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (!fs.objs.empty())
         HIP_TRY(hipMemcpy(c->d_objs.p, fs.objs.data(), fs.objs.size() * sizeof(ObjRec), hipMemcpyHostToDevice));
+    if (!fs.obj_pairs.empty())
+        HIP_TRY(hipMemcpy(c->d_opairs.p, fs.obj_pairs.data(), fs.obj_pairs.size() * sizeof(ObjPairRec),
+                          hipMemcpyHostToDevice));
     if (!fs.tri_pairs.empty())
         HIP_TRY(hipMemcpy(c->d_tris.p, fs.tri_pairs.data(), fs.tri_pairs.size() * sizeof(TriPairRec),
                           hipMemcpyHostToDevice));
@@ -463,6 +468,7 @@ int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uin
     c->scene.bvh_in_lds = (c->n_bvh_nodes <= kBvhMaxLdsNodes && fs.bvh_pair_span < 0x8000u) ? 1u : 0u;
     c->scene.bvh_pair_base = fs.bvh_pair_base;
     c->scene.objs = c->d_objs.p;
+    c->scene.obj_pairs = c->d_opairs.p;
     c->scene.tri_pairs = c->d_tris.p;
     c->scene.mats = c->d_mats.p;
     c->scene.tri_shade = c->d_tshade.p;
@@ -569,6 +575,8 @@ int pt_ctx_intersect(pt_ctx *c, const float *o, const float *d, uint32_t n, floa
     cleanup();
     return PT_OK;
 }
+
+void pt_host_sincos(float y, float *s, float *c) { sincos_f32(y, s, c); }
 
 int pt_ctx_numerics_probe(pt_ctx *c, const float *in, uint32_t n, float *out_sin, float *out_cos, float *out_sqrt,
                           float *out_rcp, uint32_t *out_philox) {

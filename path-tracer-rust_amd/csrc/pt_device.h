@@ -38,6 +38,21 @@ struct alignas(16) ObjRec {
     uint32_t pad0, pad1;
 };
 
+// Two consecutive objects of the scene in the order intersect_scene visits them (reverse index order: half 0
+// is the higher index), component-interleaved like TriPairRec: the sphere / bounding-sphere arithmetic of both
+// runs on packed instructions.  A scene with an odd object count gets a filler half that can never be hit
+// (rr = -inf makes the discriminant negative).
+struct alignas(16) ObjPairRec {
+    float cx[2], cy[2], cz[2];  // sphere: position; mesh: bounding_sphere.position + position (mod.rs:268)
+    float rr[2];                // radius.powi(2) (mod.rs:416)
+    uint32_t kind[2];
+    uint32_t pair_begin[2];     // first TriPairRec of a mesh
+    uint32_t pair_count[2];
+    int32_t bvh_root[2];
+    uint32_t obj[2];            // object index
+    uint32_t pad[2];
+};
+
 // Two consecutive triangles of one mesh (world space), component by component, read with a wave-uniform
 // index.  Each component pair sits in two adjacent dwords, so after the scalar load it is an aligned SGPR
 // pair and can be the scalar operand of a packed VALU instruction (v_pk_mul_f32 / v_pk_add_f32): one ray is
@@ -85,6 +100,7 @@ struct alignas(16) TriShade {
 
 struct DevScene {
     const ObjRec *objs;
+    const ObjPairRec *obj_pairs;  // ceil(n_objs / 2) records
     const TriPairRec *tri_pairs;
     const MatRec *mats;
     const TriShade *tri_shade;
@@ -148,7 +164,7 @@ __device__ __forceinline__ void test_pair(const TriPairRec &tr, f32x2 ox2, f32x2
     // pvec = ray.direction.cross(va_vc)                                       (mod.rs:563)
     const f32x2 px = dy2 * e2z - e2y * dz2, py = dz2 * e2x - e2z * dx2, pz = dx2 * e2y - e2x * dy2;
     const f32x2 determinant = (e1x * px + e1y * py) + e1z * pz;                // mod.rs:564
-    const f32x2 inv_det = 1.0f / determinant;                                  // mod.rs:576
+    const f32x2 inv_det = {f_rcp(determinant[0]), f_rcp(determinant[1])};      // mod.rs:576
     const f32x2 tx = ox2 - ld2(tr.ax), ty = oy2 - ld2(tr.ay), tz = oz2 - ld2(tr.az);  // mod.rs:577
     const f32x2 u = ((tx * px + ty * py) + tz * pz) * inv_det;                 // mod.rs:578
     // qvec = tvec.cross(va_vb)                                                (mod.rs:583)
@@ -158,12 +174,14 @@ __device__ __forceinline__ void test_pair(const TriPairRec &tr, f32x2 ox2, f32x2
     const f32x2 uv = u + v;
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
-        // the reference's `continue` tests, negated one by one (NaN behaves the same)
-        const bool keep = !(f_abs(determinant[hf]) < 1e-4f) && !(u[hf] < 0.0f || u[hf] > 1.0f) &&
-                          !(v[hf] < 0.0f || uv[hf] > 1.0f) && !(dist[hf] <= 0.0f);
+        // The reference's five `continue` tests (mod.rs:571,579,585,592), written as "stay" conditions.  The two
+        // forms differ only when an operand is NaN, and for a finite ray u, v, dist can only be NaN/inf when
+        // determinant == 0, which the first condition already rejects - so plain ordered compares are exact here.
+        const bool keep = (f_abs(determinant[hf]) >= 1e-4f) & (u[hf] >= 0.0f) & (u[hf] <= 1.0f) & (v[hf] >= 0.0f) &
+                          (uv[hf] <= 1.0f) & (dist[hf] > 0.0f);
         const int32_t id = (int32_t)tr.id[hf];
         const bool closer = ORDERED ? (dist[hf] < mt) : (dist[hf] < mt || (dist[hf] == mt && id < mid));
-        if (keep && closer) {
+        if (keep & closer) {
             mt = dist[hf];
             mid = id;
         }
@@ -279,6 +297,59 @@ __host__ __device__ inline size_t bvh_lds_bytes(const DevScene &S, uint32_t bloc
                         : (size_t)kBvhStack * block * sizeof(uint32_t);
 }
 
+// One object of a pair: the tail of SceneObjectData::intersect (mod.rs:261-280) + intersect_scene's replace
+// rule (mod.rs:649), given the sphere discriminant arithmetic (b, det) that was done packed for both halves.
+template <bool BVH>
+__device__ __forceinline__ void consider_object(const DevScene &S, const ObjPairRec &ob, int hf, float b, float det,
+                                                vec3 o, vec3 d, uint4 *lds, float &best_t, int32_t &best_id) {
+    const float eps = 1e-4f;
+    const float sq = f_sqrt(det);  // NaN when det < 0: both comparisons below are then false
+    const float t0 = b - sq, t1 = b + sq;
+    const bool near_ok = t0 >= eps, far_ok = t1 >= eps;
+    const bool sph_hit = !(det < 0.0f) && (near_ok || far_ok);
+    if (ob.kind[hf] == kKindSphere) {
+        const float t = near_ok ? t0 : t1;
+        if (sph_hit && t < best_t) {
+            best_t = t;
+            best_id = (int32_t)ob.obj[hf];
+        }
+        return;
+    }
+    // bounding-sphere gate (mod.rs:267-273): skip the triangle list when no lane passes
+    if (__builtin_amdgcn_ballot_w64(sph_hit) == 0ull) return;
+    float mt = __builtin_inff();
+    int32_t mid = -1;
+    const int32_t root = ob.bvh_root[hf];
+    if (BVH && root != kNoBvh && S.n_bvh_nodes != 0u) {
+        if (sph_hit) {  // per lane: divergent traversal
+            if (S.bvh_in_lds) {
+                uint16_t *stack = reinterpret_cast<uint16_t *>(lds + S.n_bvh_nodes * 4u) + threadIdx.x;
+                Stack16 codec;
+                codec.pair_base = S.bvh_pair_base;
+                bvh_closest(S, reinterpret_cast<const BvhNode *>(lds), codec, stack, blockDim.x, o, d, root, best_t, mt,
+                            mid);
+            } else {
+                uint32_t *stack = reinterpret_cast<uint32_t *>(lds) + threadIdx.x;
+                bvh_closest(S, S.bvh_nodes, Stack32(), stack, blockDim.x, o, d, root, best_t, mt, mid);
+            }
+        }
+    } else {
+        const f32x2 ox2 = splat2(o.x), oy2 = splat2(o.y), oz2 = splat2(o.z);
+        const f32x2 dx2 = splat2(d.x), dy2 = splat2(d.y), dz2 = splat2(d.z);
+        const uint32_t pb = ob.pair_begin[hf], pc = ob.pair_count[hf];
+        if (root == kNoBvh) {
+            for (uint32_t p = 0; p < pc; ++p)  // wave-uniform index -> scalar loads
+                test_pair<true>(S.tri_pairs[pb + p], ox2, oy2, oz2, dx2, dy2, dz2, mt, mid);
+        } else {  // BVH switched off for this frame: the reference's full scan over BVH-ordered records
+            for (uint32_t p = 0; p < pc; ++p) test_pair<false>(S.tri_pairs[pb + p], ox2, oy2, oz2, dx2, dy2, dz2, mt, mid);
+        }
+    }
+    if (sph_hit && mid >= 0 && mt < best_t) {
+        best_t = mt;
+        best_id = (int32_t)S.n_objs + mid;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // closest hit.  Objects in reverse index order, strict '<' (ties keep the higher object index,
 // mod.rs:637,649); inside a mesh the first triangle in list order wins ties (mod.rs:598).
@@ -288,57 +359,17 @@ template <bool BVH>
 __device__ __forceinline__ HitRec intersect_scene_dev(const DevScene &S, vec3 o, vec3 d, uint4 *lds) {
     float best_t = __builtin_inff();
     int32_t best_id = -1;
-    const float eps = 1e-4f;
-    for (int i = (int)S.n_objs - 1; i >= 0; --i) {
-        const ObjRec ob = S.objs[i];  // wave-uniform -> scalar loads
-        const vec3 op = mk(ob.cx, ob.cy, ob.cz) - o;
-        const float b = dot(op, d);
-        const float det = b * b - dot(op, op) + ob.rr;
-        const float sq = f_sqrt(det);  // NaN when det < 0: both comparisons below are then false
-        const float t0 = b - sq, t1 = b + sq;
-        const bool near_ok = t0 >= eps, far_ok = t1 >= eps;
-        const bool sph_hit = !(det < 0.0f) && (near_ok || far_ok);
-        if (ob.kind == kKindSphere) {
-            const float t = near_ok ? t0 : t1;
-            if (sph_hit && t < best_t) {
-                best_t = t;
-                best_id = i;
-            }
-        } else {
-            // bounding-sphere gate (mod.rs:267-273): skip the triangle list when no lane passes
-            if (__builtin_amdgcn_ballot_w64(sph_hit) != 0ull) {
-                float mt = __builtin_inff();
-                int32_t mid = -1;
-                if (BVH && ob.bvh_root != kNoBvh && S.n_bvh_nodes != 0u) {
-                    if (sph_hit) {  // per lane: divergent traversal
-                        if (S.bvh_in_lds) {
-                            uint16_t *stack = reinterpret_cast<uint16_t *>(lds + S.n_bvh_nodes * 4u) + threadIdx.x;
-                            Stack16 codec;
-                            codec.pair_base = S.bvh_pair_base;
-                            bvh_closest(S, reinterpret_cast<const BvhNode *>(lds), codec, stack, blockDim.x, o, d,
-                                        ob.bvh_root, best_t, mt, mid);
-                        } else {
-                            uint32_t *stack = reinterpret_cast<uint32_t *>(lds) + threadIdx.x;
-                            bvh_closest(S, S.bvh_nodes, Stack32(), stack, blockDim.x, o, d, ob.bvh_root, best_t, mt, mid);
-                        }
-                    }
-                } else {
-                    const f32x2 ox2 = splat2(o.x), oy2 = splat2(o.y), oz2 = splat2(o.z);
-                    const f32x2 dx2 = splat2(d.x), dy2 = splat2(d.y), dz2 = splat2(d.z);
-                    if (ob.bvh_root == kNoBvh) {
-                        for (uint32_t p = 0; p < ob.pair_count; ++p)  // wave-uniform index -> scalar loads
-                            test_pair<true>(S.tri_pairs[ob.pair_begin + p], ox2, oy2, oz2, dx2, dy2, dz2, mt, mid);
-                    } else {  // BVH switched off for this frame: the reference's full scan over BVH-ordered records
-                        for (uint32_t p = 0; p < ob.pair_count; ++p)
-                            test_pair<false>(S.tri_pairs[ob.pair_begin + p], ox2, oy2, oz2, dx2, dy2, dz2, mt, mid);
-                    }
-                }
-                if (sph_hit && mid >= 0 && mt < best_t) {
-                    best_t = mt;
-                    best_id = (int32_t)S.n_objs + mid;
-                }
-            }
-        }
+    const f32x2 ox2 = splat2(o.x), oy2 = splat2(o.y), oz2 = splat2(o.z);
+    const f32x2 dx2 = splat2(d.x), dy2 = splat2(d.y), dz2 = splat2(d.z);
+    const uint32_t n_pairs = (S.n_objs + 1u) >> 1;
+    for (uint32_t p = 0; p < n_pairs; ++p) {
+        const ObjPairRec ob = S.obj_pairs[p];  // wave-uniform -> scalar loads
+        // intersect_sphere's discriminant (mod.rs:413-416) for both objects of the pair
+        const f32x2 opx = ld2(ob.cx) - ox2, opy = ld2(ob.cy) - oy2, opz = ld2(ob.cz) - oz2;
+        const f32x2 b = (opx * dx2 + opy * dy2) + opz * dz2;
+        const f32x2 det = (b * b - ((opx * opx + opy * opy) + opz * opz)) + ld2(ob.rr);
+        consider_object<BVH>(S, ob, 0, b[0], det[0], o, d, lds, best_t, best_id);
+        consider_object<BVH>(S, ob, 1, b[1], det[1], o, d, lds, best_t, best_id);
     }
     HitRec h;
     h.t = best_t;

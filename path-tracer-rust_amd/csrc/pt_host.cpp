@@ -332,6 +332,27 @@ bool flatten_scene(const pt_camera &cam, const pt_object *objs, uint32_t n_objs,
         m.pz = position.z;
         m.reflect = o.reflect_type;
     }
+    // pairs in visiting order (mod.rs:637: highest index first)
+    out.obj_pairs.assign((n_objs + 1u) / 2u, ObjPairRec{});
+    for (uint32_t v = 0; v < 2u * (uint32_t)out.obj_pairs.size(); ++v) {
+        ObjPairRec &pr = out.obj_pairs[v / 2u];
+        const uint32_t hf = v & 1u;
+        if (v < n_objs) {
+            const ObjRec &r = out.objs[n_objs - 1u - v];
+            pr.cx[hf] = r.cx, pr.cy[hf] = r.cy, pr.cz[hf] = r.cz, pr.rr[hf] = r.rr;
+            pr.kind[hf] = r.kind;
+            pr.pair_begin[hf] = r.pair_begin;
+            pr.pair_count[hf] = r.pair_count;
+            pr.bvh_root[hf] = r.bvh_root;
+            pr.obj[hf] = n_objs - 1u - v;
+        } else {  // filler: a sphere whose discriminant is -inf for every finite ray
+            pr.cx[hf] = pr.cy[hf] = pr.cz[hf] = 0.0f;
+            pr.rr[hf] = -std::numeric_limits<float>::infinity();
+            pr.kind[hf] = kKindSphere;
+            pr.bvh_root[hf] = kNoBvh;
+            pr.obj[hf] = 0;
+        }
+    }
     return true;
 }
 

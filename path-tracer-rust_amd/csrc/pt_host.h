@@ -15,6 +15,7 @@ namespace host {
 
 struct FlatScene {
     std::vector<ObjRec> objs;
+    std::vector<ObjPairRec> obj_pairs;
     std::vector<TriPairRec> tri_pairs;
     std::vector<MatRec> mats;
     std::vector<TriShade> tri_shade;

@@ -311,7 +311,7 @@ __global__ void k_numerics(const float *__restrict__ in, uint32_t n, float *__re
     out_sin[i] = s;
     out_cos[i] = c;
     out_sqrt[i] = f_sqrt(v);
-    out_rcp[i] = 1.0f / v;
+    out_rcp[i] = f_rcp(v);
     const u32x4 r = draw_block(0x0123456789abcdefull, i, __float_as_uint(v), (i << 8) | (i & 15u));
     out_philox[4 * i + 0] = r.a;
     out_philox[4 * i + 1] = r.b;

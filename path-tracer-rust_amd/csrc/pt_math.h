@@ -49,13 +49,49 @@ PT_HD float dot(vec3 a, vec3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 PT_HD vec3 cross(vec3 a, vec3 b) {
     return mk(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
 }
-// IEEE correctly rounded on both sides: x86 sqrtss, and llvm.sqrt.f32 under
-// -fhip-fp32-correctly-rounded-divide-sqrt (HIP's __fsqrt_rn is the 1-ulp native v_sqrt_f32: not usable)
+// IEEE correctly rounded square root and reciprocal on both sides (x86: sqrtss / divss).
+// On the device these are hipcc's own correctly-rounded expansions (-fhip-fp32-correctly-rounded-divide-sqrt)
+// with the input-scaling steps taken out of the common path:
+//   f_sqrt: v_sqrt_f32 (<= 1 ulp) then the two-neighbour fma residual test, exactly as LLVM lowers llvm.sqrt.f32;
+//           LLVM first multiplies inputs below 2^-96 by 2^32 (the residuals would underflow).  Here the whole
+//           wave takes the full llvm.sqrt.f32 path only if some lane really holds 0 < x < 2^-96 (a tangent ray's
+//           discriminant can), otherwise the 5 scaling instructions are skipped.  +-0, +inf, NaN and negative
+//           inputs come out of the short path as IEEE requires (checked lane by lane in the tests).
+//   f_rcp : LLVM's f32 division with numerator 1: v_rcp_f32, one Newton step, then the quotient/residual fmas.
+//           v_div_scale / v_div_fmas / v_div_fixup only matter when the divisor is denormal, zero, inf, NaN or
+//           |d| > 2^126; callers guarantee a normal in-range divisor wherever the result is used (vector lengths
+//           of scene-scale vectors; determinants that passed |det| >= 1e-4), so the three are dropped.
+// HIP's __fsqrt_rn / __frcp_rn are the 1-ulp native ops and are not usable (tests caught it).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ float f_sqrt(float x) {
+    const uint32_t bits = __float_as_uint(x);
+    // 0 < |x| < 2^-96  <=>  (bits & 0x7fffffff) in [1, 0x0F800000)   (negative tiny inputs too: the native op
+    // flushes -denormal to -0 where IEEE wants NaN)
+    if (__builtin_amdgcn_ballot_w64(((bits & 0x7fffffffu) - 1u) < 0x0F7FFFFFu) != 0ull) return __builtin_sqrtf(x);
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
+    float r = r_dn <= 0.0f ? s_dn : s;
+    r = r_up > 0.0f ? s_up : r;
+    return r;
+}
+__device__ __forceinline__ float f_rcp(float d) {
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e0 = __builtin_fmaf(-d, r0, 1.0f);
+    const float r1 = __builtin_fmaf(e0, r0, r0);
+    const float e1 = __builtin_fmaf(-d, r1, 1.0f);
+    const float q1 = __builtin_fmaf(e1, r1, r1);
+    const float e2 = __builtin_fmaf(-d, q1, 1.0f);
+    return __builtin_fmaf(e2, r1, q1);
+}
+#else
 PT_HD float f_sqrt(float x) { return __builtin_sqrtf(x); }
+PT_HD float f_rcp(float d) { return 1.0f / d; }
+#endif
 PT_HD float f_abs(float x) { return __builtin_fabsf(x); }
 PT_HD float f_max(float a, float b) { return __builtin_fmaxf(a, b); }
 PT_HD float length(vec3 a) { return f_sqrt(dot(a, a)); }
-PT_HD vec3 normalize(vec3 a) { return a * (1.0f / length(a)); }
+PT_HD vec3 normalize(vec3 a) { return a * f_rcp(length(a)); }
 
 // ---- rand 0.8.5: 24 high bits of a u32 -> [0,1)
 PT_HD float unit_f32(uint32_t u) { return (float)(u >> 8) * (1.0f / 16777216.0f); }
@@ -65,19 +101,13 @@ struct u32x4 {
     uint32_t a, b, c, d;
 };
 
-PT_HD uint32_t mulhi32(uint32_t a, uint32_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __umulhi(a, b);
-#else
-    return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32);
-#endif
-}
-
 PT_HD u32x4 philox4x32_10(u32x4 ctr, uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int round = 0; round < 10; ++round) {
-        const uint32_t hi0 = mulhi32(0xD2511F53u, ctr.a), lo0 = 0xD2511F53u * ctr.a;
-        const uint32_t hi1 = mulhi32(0xCD9E8D57u, ctr.c), lo1 = 0xCD9E8D57u * ctr.c;
+        // one 32x32->64 multiply per word pair (v_mad_u64_u32 on gfx950) instead of separate mul_hi / mul_lo
+        const uint64_t p0 = (uint64_t)0xD2511F53u * ctr.a, p1 = (uint64_t)0xCD9E8D57u * ctr.c;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         u32x4 nx;
         nx.a = hi1 ^ ctr.b ^ k0;
         nx.b = lo1;
@@ -135,36 +165,25 @@ PT_HD float cos_poly(double x2, bool flip) {
 }
 }  // namespace sc
 
-// sine and cosine of one argument share the range reduction (same results as two separate calls)
+// Sine and cosine of one argument, sharing the range reduction; valid for 0 <= y < 120.
+// glibc keeps two shortcuts for small |y| (|y| < pi/4: no reduction; |y| < 2^-12: return y / 1).  Both are
+// arithmetic no-ops on this domain: for y < pi/4 the reduction yields n = 0 and x - 0*hpi = x exactly, and for
+// y < 2^-12 the polynomials round back to y and 1.0f.  So one branch-free path gives bit-identical results
+// (checked against the two-shortcut restatement in the oracle, and through it against the platform libm, on all
+// 2^24 reachable arguments: tests/test_abi.py) and the wave never runs two copies of the polynomials.
 PT_HD void sincos_f32(float y, float *s_out, float *c_out) {
     double x = (double)y;
-    if (sc::top12(y) < sc::top12(0x1.921FB6p-1f)) {
-        if (sc::top12(y) < sc::top12(0x1p-12f)) {
-            *s_out = y;
-            *c_out = 1.0f;
-            return;
-        }
-        const double x2 = x * x;
-        *s_out = sc::sin_poly(x, x2);
-        *c_out = sc::cos_poly(x2, false);
-        return;
-    }
     const double r = x * sc::kHpiInv;
     const int n = ((int32_t)r + 0x800000) >> 24;
     x = x - (double)n * sc::kHpi;
     const int q = n & 3;
     const double sgn = (q == 1 || q == 2) ? -1.0 : 1.0;
-    const double xs = x * sgn;
-    const double x2 = x * x;
-    const bool flip = (n & 2) != 0;
+    const float sp = sc::sin_poly(x * sgn, x * x);
+    const float cp = sc::cos_poly(x * x, (n & 2) != 0);
     // sinf uses polynomial index n, cosf uses n^1: even -> sine polynomial, odd -> cosine polynomial
-    if ((n & 1) == 0) {
-        *s_out = sc::sin_poly(xs, x2);
-        *c_out = sc::cos_poly(x2, flip);
-    } else {
-        *s_out = sc::cos_poly(x2, flip);
-        *c_out = sc::sin_poly(xs, x2);
-    }
+    const bool even = (n & 1) == 0;
+    *s_out = even ? sp : cp;
+    *c_out = even ? cp : sp;
 }
 
 // tent filter of render_pixel (mod.rs:820-830)

@@ -159,6 +159,9 @@ def product():
     L.pt_ctx_render.argtypes = [C.c_void_p, C.POINTER(PtConfig), C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.POINTER(PtStats)]
     L.pt_ctx_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.pt_host_sincos.argtypes = [C.c_float, fp, fp]
+    L.pt_host_sincos.restype = None
+    L.pt_ctx_numerics_probe.argtypes = [C.c_void_p, fp, C.c_uint32, fp, fp, fp, fp, u32p]
     L.pt_ctx_intersect.argtypes = [C.c_void_p, fp, fp, C.c_uint32, fp, i32p, i32p, fp, fp]
     L.pt_render.argtypes = [C.POINTER(PtConfig), C.POINTER(PtCamera), C.POINTER(PtObject), C.c_uint32,
                             C.POINTER(PtTriangle), C.c_uint32, fp, C.c_void_p, C.c_void_p, C.c_void_p,

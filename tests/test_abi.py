@@ -114,3 +114,30 @@ def test_invalid_arguments_return_codes():
     h = C.c_void_p()
     assert L.pt_scene_load(b"/nonexistent/x.json", b".", C.byref(h)) == -6
     assert L.pt_write_ppm(b"/nonexistent_dir/x.ppm", _np_f(np.zeros(3, np.float32)), 1, 1, 1, b"s", 0) == -6
+
+
+def test_product_sincos_equals_oracle_on_whole_domain():
+    """The kernels' branch-free sincos (csrc/pt_math.h, host instantiation) against the oracle's restatement of
+    glibc's sinf/cosf on every reachable argument 2*PI*(k*2^-24): bit-identical (the oracle itself equals the
+    platform libm there, tests/test_oracle.py)."""
+    import subprocess, tempfile, textwrap
+    src = textwrap.dedent("""
+        #include <stdio.h>
+        #include <string.h>
+        #include <stdint.h>
+        float pto_sinf(float); float pto_cosf(float); void pt_host_sincos(float, float*, float*);
+        int main(void) { const float two_pi = 2.0f * 3.141592653589793f; long bad = 0;
+          for (uint32_t k = 0; k < (1u << 24); k++) { float a = two_pi * ((float)k * (1.0f / 16777216.0f)), s, c;
+            pt_host_sincos(a, &s, &c); float s0 = pto_sinf(a), c0 = pto_cosf(a);
+            bad += memcmp(&s, &s0, 4) != 0; bad += memcmp(&c, &c0, 4) != 0; }
+          printf("%ld ", bad); return bad != 0; }
+    """)
+    with tempfile.TemporaryDirectory() as td:
+        cfile = os.path.join(td, "chk.c")
+        open(cfile, "w").write(src)
+        exe = os.path.join(td, "chk")
+        subprocess.check_call(["gcc", "-O2", cfile, "-o", exe, ptlib.PRODUCT_SO, ptlib.ORACLE_SO,
+                               "-Wl,-rpath," + os.path.dirname(ptlib.PRODUCT_SO),
+                               "-Wl,-rpath," + os.path.dirname(ptlib.ORACLE_SO), "-lm"])
+        out = subprocess.check_output([exe]).decode().strip()
+    assert out == "0"

@@ -69,8 +69,31 @@ def test_device_numerics_contract(gpu):
     assert np.array_equal(c[:20000].view(np.uint32), want_c.view(np.uint32))
     # IEEE sqrt and division are correctly rounded on both sides: compare against numpy f32
     assert np.array_equal(q.view(np.uint32), np.sqrt(x).view(np.uint32))
-    with np.errstate(divide="ignore"):
-        assert np.array_equal(r.view(np.uint32), (np.float32(1.0) / x).view(np.uint32))
+    ok = x >= np.float32(2.0 ** -126)  # f_rcp's contract: normal, in-range divisors
+    assert np.array_equal(r[ok].view(np.uint32), (np.float32(1.0) / x[ok]).view(np.uint32))
+    # the device's short correctly-rounded sqrt / reciprocal sequences over the whole exponent range, including
+    # the inputs that force the scaled path (0 < x < 2^-96), denormals, zeros, infinities, negatives and NaN
+    m = 400000
+    bits = rng.integers(0, 1 << 32, size=m, dtype=np.uint64).astype(np.uint32)
+    y = bits.view(np.float32).copy()
+    y[:12] = [0.0, -0.0, np.inf, -np.inf, np.nan, 1e-30, 1.4e-45, 1e-38, 2.0 ** -96, np.float32(2.0 ** -96) * np.float32(0.9999999),
+              1.0, 3.4e38]
+    y[12:20000] = np.abs(y[12:20000])  # plenty of positive values (sqrt domain)
+    s2, c2, q2, r2 = (np.zeros(m, np.float32) for _ in range(4))
+    ph2 = np.zeros(4 * m, np.uint32)
+    rc = L.pt_ctx_numerics_probe(ctx, _np_f(y), m, _np_f(s2), _np_f(c2), _np_f(q2), _np_f(r2),
+                                 ph2.ctypes.data_as(ptlib.u32p))
+    assert rc == 0, L.pt_last_error()
+    with np.errstate(all="ignore"):
+        want_q = np.sqrt(y)
+        want_r = np.float32(1.0) / y
+    nan_q = np.isnan(want_q)
+    assert np.array_equal(np.isnan(q2), nan_q)
+    assert np.array_equal(q2[~nan_q].view(np.uint32), want_q[~nan_q].view(np.uint32))
+    ay = np.abs(y)
+    dom = np.isfinite(y) & (ay >= np.float32(2.0 ** -126)) & (ay <= np.float32(2.0 ** 126))  # f_rcp's contract
+    assert dom.sum() > 0.9 * m * 0.98
+    assert np.array_equal(r2[dom].view(np.uint32), want_r[dom].view(np.uint32))
     out = (C.c_uint32 * 4)()
     for i in list(range(64)) + [n - 1]:
         ctr = (C.c_uint32 * 4)(i, int(x[i:i + 1].view(np.uint32)[0]), ((i << 8) | (i & 15)) & 0xffffffff, 0)
