@@ -142,6 +142,8 @@ FrameParams make_frame(const pt_ctx *ctx, const pt_config *cfg, uint32_t idx_beg
     F.sv_x = sv[0];
     F.sv_y = sv[1];
     F.sv_z = sv[2];
+    F.debug = 0;
+    if (const char *e = getenv("PT_DEBUG")) F.debug = (uint32_t)atoi(e);
     return F;
 }
 
@@ -175,17 +177,17 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &F, hipS
     uint32_t spp_pass = (uint32_t)(want / npix);
     if (spp_pass == 0) spp_pass = 1;
     if (spp_pass > cfg->spp) spp_pass = cfg->spp;
-    const uint64_t n_primary_max = npix * spp_pass;
-    if (n_primary_max > 0xffffffffull / 8) {
+    // stream b owns m consecutive pixels of the band (all samples of a pass): about 2048 streams, at most
+    // kMaxStreamPixels pixels each (their radiance accumulators live in LDS inside k_shade)
+    uint32_t m = (uint32_t)((npix + 2047) / 2048);
+    if (m > kMaxStreamPixels) m = kMaxStreamPixels;
+    const uint32_t K = (uint32_t)((npix + m - 1) / m);
+    // a primary ray has at most 4 descendants alive at one depth (two refract splits, mod.rs:760)
+    const uint64_t cap64 = (4ull * m * spp_pass + kBlock - 1) / kBlock * kBlock;
+    if (cap64 * K > 0xffffffffull / 2) {
         set_error("rays per pass too large");
         return PT_ERR_INVALID;
     }
-    const uint64_t n_chunks = (n_primary_max + kBlock - 1) / kBlock;
-    uint32_t K = 2048;
-    if (n_chunks < K) K = (uint32_t)n_chunks;
-    const uint64_t chunks_per_stream = (n_chunks + K - 1) / K;
-    // a primary ray has at most 4 descendants alive at one depth (two refract splits, mod.rs:760)
-    const uint64_t cap64 = 4 * chunks_per_stream * kBlock;
     const uint32_t cap = (uint32_t)cap64;
     const size_t slots = (size_t)K * cap;
     for (int w = 0; w < 2; ++w) {
@@ -228,8 +230,7 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &F, hipS
         if (cb && p >= 2) cb(user, (float)(p - 1) / (float)n_pass);
         const uint32_t s0 = p * spp_pass;
         const uint32_t s_here = (cfg->spp - s0) < spp_pass ? (cfg->spp - s0) : spp_pass;
-        const uint64_t n_primary = npix * s_here;
-        launch_generate(st, K, F, queue_of(c, 0), c->cnt.p, cap, s0, n_primary);
+        launch_generate(st, K, F, queue_of(c, 0), c->cnt.p, cap, s0, s_here, m);
         for (int d = 0; d < n_depth; ++d) {
             const RayQueue qin = queue_of(c, d & 1), qout = queue_of(c, (d + 1) & 1);
             if (c->profiling) {
@@ -246,7 +247,7 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &F, hipS
                 launch_intersect(st, K, c->scene, qin, c->hit.p, c->cnt.p + (size_t)d * K, cap, c->blk_rays.p);
             }
             launch_shade(st, K, c->scene, F, qin, qout, c->hit.p, c->cnt.p + (size_t)d * K,
-                         c->cnt.p + (size_t)(d + 1) * K, cap, c->acc.p, c->flags.p);
+                         c->cnt.p + (size_t)(d + 1) * K, cap, c->acc.p, c->flags.p, m);
         }
         HIP_TRY(hipEventRecord(pass_done[p & 1], st));
         ++passes_done;

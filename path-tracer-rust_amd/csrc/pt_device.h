@@ -122,6 +122,7 @@ struct FrameParams {
     float lens_x, lens_y, lens_z;  // lens_center()
     float su_x, su_y, su_z;        // orthogonals().0
     float sv_x, sv_y, sv_z;        // orthogonals().1
+    uint32_t debug;                // ablation switches for profiling builds (PT_DEBUG env): 0 in production
 };
 
 // ray meta word: sample index (24 bits) | depth (4 bits) | branch id (3 bits)

@@ -8,6 +8,7 @@
 namespace pt {
 
 constexpr uint32_t kBlock = 256;    // 4 waves of 64
+constexpr uint32_t kMaxStreamPixels = 1024;  // pixels owned by one stream (24 KiB of LDS accumulators at most)
 constexpr uint32_t kLevels = 13;    // ray depths 0..11 plus the (always empty) level written by the last shade
 
 // SoA-of-packets ray queue; every array holds K streams of `cap` slots (see pt_kernels.hip)
@@ -19,12 +20,12 @@ struct RayQueue {
 };
 
 void launch_generate(hipStream_t st, uint32_t K, const FrameParams &F, const RayQueue &q, uint32_t *cnt0,
-                     uint32_t cap, uint32_t s0, uint64_t n_primary);
+                     uint32_t cap, uint32_t s0, uint32_t s_here, uint32_t m);
 void launch_intersect(hipStream_t st, uint32_t K, const DevScene &S, const RayQueue &q, float2 *hit,
                       const uint32_t *cnt, uint32_t cap, unsigned long long *blk_rays);
 void launch_shade(hipStream_t st, uint32_t K, const DevScene &S, const FrameParams &F, const RayQueue &qin,
                   const RayQueue &qout, const float2 *hit, const uint32_t *cnt_in, uint32_t *cnt_out, uint32_t cap,
-                  unsigned long long *acc, uint32_t *flags);
+                  unsigned long long *acc, uint32_t *flags, uint32_t m);
 void launch_resolve(hipStream_t st, const unsigned long long *acc, float *out, uint32_t npix, uint32_t spp);
 void launch_mega(hipStream_t st, uint32_t grid, const DevScene &S, const FrameParams &F, unsigned long long *acc,
                  uint32_t chunk_spp, uint32_t n_chunks, unsigned long long *total_rays);

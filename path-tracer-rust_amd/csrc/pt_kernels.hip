@@ -15,8 +15,11 @@
 //   * compaction needs no global atomic at all: wave ballot + mbcnt prefix gives the slot inside the
 //     wave, one LDS add per wave orders the waves of the workgroup, and the stream length is a plain
 //     store at the end (a single global tail counter would saturate at ~90 M atomics/s on this chip),
-//   * K >> 256 CUs workgroups keep every XCD busy; a stream holds thousands of rays taken round-robin
-//     (256-ray chunks) from the whole pass, so all streams shrink at the same rate with depth.
+//   * stream b owns the pixels [b*m, (b+1)*m) of the band (all samples of the pass): every contribution to
+//     those pixels is produced by workgroup b, so radiance is summed with LDS atomics inside a launch and
+//     flushed to the frame accumulator by plain read-modify-write stores - no global atomic in the pipeline
+//     (global 64-bit atomics cost 27 % of k_shade when they were used: profiles/README.md),
+//   * K >> 256 CUs workgroups keep every XCD busy and the hardware dispatcher balances streams of unequal decay.
 // Queue arrays (per ray): od0 = (ox,oy,oz,dx) 16 B, od1 = (dy,dz) 8 B, tp = (throughput rgb, pixel) 16 B,
 // meta 4 B; hit = (t, id) 8 B.  intersect moves 24+8 = 32 B/ray, shade 52 B in + 44 B out per survivor.
 #include "pt_kernels.h"
@@ -41,24 +44,20 @@ __device__ __forceinline__ void store_ray(const RayQueue &q, size_t at, vec3 o, 
 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_generate(FrameParams F, RayQueue q, uint32_t *__restrict__ cnt0,
-                                                     uint32_t cap, uint32_t s0, uint64_t n_primary) {
-    const uint32_t b = blockIdx.x, K = gridDim.x, tid = threadIdx.x;
+                                                     uint32_t cap, uint32_t s0, uint32_t s_here, uint32_t m) {
+    // stream b = pixels [b*m, min((b+1)*m, npix)) x samples [s0, s0+s_here); lane order: pixel fastest
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
     const size_t base = (size_t)b * cap;
-    uint32_t count = 0;
-    for (uint32_t j = 0;; ++j) {
-        const uint64_t first = ((uint64_t)j * K + b) * kBlock;  // 256-ray chunks dealt round-robin to streams
-        if (first >= n_primary) break;
-        const uint64_t g = first + tid;
-        if (g < n_primary) {
-            const uint32_t pl = (uint32_t)(g % F.npix);
-            const uint32_t s = s0 + (uint32_t)(g / F.npix);
-            const PathRay r = primary_ray(F, F.idx_begin + pl, s);
-            store_ray(q, base + (size_t)j * kBlock + tid, r.o, r.d, r.thr, r.pix, r.meta);
-        }
-        const uint64_t left = n_primary - first;
-        count += left < kBlock ? (uint32_t)left : kBlock;
+    const uint32_t p0 = b * m;
+    const uint32_t mb = p0 < F.npix ? ((F.npix - p0) < m ? (F.npix - p0) : m) : 0u;
+    const uint32_t n = mb * s_here;
+    for (uint32_t g = tid; g < n; g += kBlock) {
+        const uint32_t pl = p0 + g % mb;
+        const uint32_t s = s0 + g / mb;
+        const PathRay r = primary_ray(F, F.idx_begin + pl, s);
+        store_ray(q, base + g, r.o, r.d, r.thr, r.pix, r.meta);
     }
-    if (tid == 0) cnt0[b] = count;
+    if (tid == 0) cnt0[b] = n;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -80,12 +79,12 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, RayQueue q, fl
 }
 
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void add_radiance(unsigned long long *__restrict__ acc, uint32_t npix, uint32_t pl,
-                                             vec3 v) {
+// radiance of the stream's own pixels, summed in LDS (u64 32.32 fixed point, [3][m])
+__device__ __forceinline__ void add_radiance_lds(unsigned long long *lds_acc, uint32_t m, uint32_t slot, vec3 v) {
     const uint64_t r = to_fixed(v.x), g = to_fixed(v.y), bl = to_fixed(v.z);
-    if (r) atomicAdd(&acc[pl], (unsigned long long)r);
-    if (g) atomicAdd(&acc[(size_t)npix + pl], (unsigned long long)g);
-    if (bl) atomicAdd(&acc[2 * (size_t)npix + pl], (unsigned long long)bl);
+    if (r) atomicAdd(&lds_acc[slot], (unsigned long long)r);
+    if (g) atomicAdd(&lds_acc[m + slot], (unsigned long long)g);
+    if (bl) atomicAdd(&lds_acc[2u * m + slot], (unsigned long long)bl);
 }
 
 __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, FrameParams F, RayQueue qin, RayQueue qout,
@@ -93,38 +92,70 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, FrameParams F, Ray
                                                   const uint32_t *__restrict__ cnt_in,
                                                   uint32_t *__restrict__ cnt_out, uint32_t cap,
                                                   unsigned long long *__restrict__ acc,
-                                                  uint32_t *__restrict__ flags) {
-    __shared__ uint32_t s_tail;
+                                                  uint32_t *__restrict__ flags, uint32_t m) {
+    // dynamic LDS: [u64 acc: 3*m][u32 tail]
+    unsigned long long *lds_acc = reinterpret_cast<unsigned long long *>(dyn_lds);
+    uint32_t *s_tail_p = reinterpret_cast<uint32_t *>(lds_acc + 3u * m);
+#define s_tail (*s_tail_p)
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t n = cnt_in[b];
+    if (n == 0u) {  // an empty stream leaves an empty stream
+        if (tid == 0) cnt_out[b] = 0u;
+        return;
+    }
+    for (uint32_t k = tid; k < 3u * m; k += kBlock) lds_acc[k] = 0ull;
     if (tid == 0) s_tail = 0;
     __syncthreads();
-    const uint32_t n = cnt_in[b];
+    const uint32_t p0 = b * m;  // first pixel (band-local) of this stream
     const size_t base = (size_t)b * cap;
     bool overflow = false;
+    // Software pipeline over the stream: the five loads of chunk j+1 are issued (unconditionally, whatever the
+    // hit record says - a miss costs 44 unused bytes on < 5 % of the rays) before chunk j is shaded, so a wave
+    // exposes one memory latency per chunk instead of two dependent ones.
+    float2 n_hr = make_float2(0.0f, __int_as_float(-1));
+    float4 n_a = make_float4(0, 0, 0, 0), n_tp = n_a;
+    float2 n_c = make_float2(0, 0);
+    uint32_t n_meta = 0;
+    if (tid < n) {
+        n_hr = hit[base + tid];
+        n_a = qin.od0[base + tid];
+        n_c = qin.od1[base + tid];
+        n_tp = qin.tp[base + tid];
+        n_meta = qin.meta[base + tid];
+    }
     for (uint32_t j0 = 0; j0 < n; j0 += kBlock) {  // uniform trip count: every lane reaches the ballots
         const uint32_t i = j0 + tid;
+        const float2 hr = n_hr;
+        const float4 a = n_a, tp = n_tp;
+        const float2 c = n_c;
+        const uint32_t meta = n_meta;
+        const uint32_t i_next = i + kBlock;
+        if (i_next < n) {
+            n_hr = hit[base + i_next];
+            n_a = qin.od0[base + i_next];
+            n_c = qin.od1[base + i_next];
+            n_tp = qin.tp[base + i_next];
+            n_meta = qin.meta[base + i_next];
+        }
         ShadeOut so;
         so.n_rays = 0;
         so.emits = false;
         uint32_t pix = 0;
         if (i < n) {
-            const float2 hr = hit[base + i];
             HitRec h;
             h.t = hr.x;
             h.id = __float_as_int(hr.y);
             if (h.id >= 0) {
-                const float4 a = qin.od0[base + i];
-                const float2 c = qin.od1[base + i];
-                const float4 tp = qin.tp[base + i];
                 PathRay in;
                 in.o = mk(a.x, a.y, a.z);
                 in.d = mk(a.w, c.x, c.y);
                 in.thr = mk(tp.x, tp.y, tp.z);
                 in.pix = __float_as_uint(tp.w);
-                in.meta = qin.meta[base + i];
+                in.meta = meta;
                 pix = in.pix;
                 shade_hit(S, F, in, h, so);
-                if (so.emits) add_radiance(acc, F.npix, in.pix - F.idx_begin, so.contrib);
+                if (so.emits && !(F.debug & 1u)) add_radiance_lds(lds_acc, m, in.pix - F.idx_begin - p0, so.contrib);
+                if (F.debug & 1u) asm volatile("" ::"v"(so.contrib.x), "v"(so.contrib.y), "v"(so.contrib.z));
             }
         }
         // stream compaction: survivors first (path order kept inside the wave), split children after them
@@ -152,6 +183,14 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, FrameParams F, Ray
     if (overflow) atomicOr(flags, 1u);
     __syncthreads();
     if (tid == 0) cnt_out[b] = s_tail < cap ? s_tail : cap;
+    // flush: this workgroup is the only writer of its pixels, launches on the stream are ordered
+    const uint32_t mb = (F.npix - p0) < m ? (F.npix - p0) : m;
+    for (uint32_t k = tid; k < 3u * mb; k += kBlock) {
+        const uint32_t c = k / mb, p = k - c * mb;
+        const unsigned long long v = lds_acc[c * m + p];
+        if (v) acc[(size_t)c * F.npix + p0 + p] += v;
+    }
+#undef s_tail
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -321,8 +360,8 @@ __global__ void k_numerics(const float *__restrict__ in, uint32_t n, float *__re
 
 // ------------------------------------------------------------------------------------------------ launchers
 void launch_generate(hipStream_t st, uint32_t K, const FrameParams &F, const RayQueue &q, uint32_t *cnt0,
-                     uint32_t cap, uint32_t s0, uint64_t n_primary) {
-    hipLaunchKernelGGL(k_generate, dim3(K), dim3(kBlock), 0, st, F, q, cnt0, cap, s0, n_primary);
+                     uint32_t cap, uint32_t s0, uint32_t s_here, uint32_t m) {
+    hipLaunchKernelGGL(k_generate, dim3(K), dim3(kBlock), 0, st, F, q, cnt0, cap, s0, s_here, m);
 }
 void launch_intersect(hipStream_t st, uint32_t K, const DevScene &S, const RayQueue &q, float2 *hit,
                       const uint32_t *cnt, uint32_t cap, unsigned long long *blk_rays) {
@@ -334,9 +373,10 @@ void launch_intersect(hipStream_t st, uint32_t K, const DevScene &S, const RayQu
 }
 void launch_shade(hipStream_t st, uint32_t K, const DevScene &S, const FrameParams &F, const RayQueue &qin,
                   const RayQueue &qout, const float2 *hit, const uint32_t *cnt_in, uint32_t *cnt_out, uint32_t cap,
-                  unsigned long long *acc, uint32_t *flags) {
-    hipLaunchKernelGGL(k_shade, dim3(K), dim3(kBlock), 0, st, S, F, qin, qout, hit, cnt_in, cnt_out, cap, acc,
-                       flags);
+                  unsigned long long *acc, uint32_t *flags, uint32_t m) {
+    const size_t lds = (size_t)3 * m * sizeof(unsigned long long) + 16;
+    hipLaunchKernelGGL(k_shade, dim3(K), dim3(kBlock), lds, st, S, F, qin, qout, hit, cnt_in, cnt_out, cap, acc,
+                       flags, m);
 }
 void launch_resolve(hipStream_t st, const unsigned long long *acc, float *out, uint32_t npix, uint32_t spp) {
     hipLaunchKernelGGL(k_resolve, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, st, acc, out, npix, spp);
