@@ -173,7 +173,7 @@ double now_ms() {
 int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &F, hipStream_t st,
                      const volatile uint8_t *cancel, pt_progress_fn cb, void *user, pt_stats *stats) {
     const uint64_t npix = F.npix;
-    uint64_t want = cfg->rays_per_pass ? cfg->rays_per_pass : (8u << 20);
+    uint64_t want = cfg->rays_per_pass ? cfg->rays_per_pass : (32u << 20);  // ~12 GB of queues: sized for 288 GB HBM
     uint32_t spp_pass = (uint32_t)(want / npix);
     if (spp_pass == 0) spp_pass = 1;
     if (spp_pass > cfg->spp) spp_pass = cfg->spp;
