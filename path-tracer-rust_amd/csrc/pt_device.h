@@ -178,8 +178,10 @@ __device__ __forceinline__ void test_pair(const TriPairRec &tr, f32x2 ox2, f32x2
         // The reference's five `continue` tests (mod.rs:571,579,585,592), written as "stay" conditions.  The two
         // forms differ only when an operand is NaN, and for a finite ray u, v, dist can only be NaN/inf when
         // determinant == 0, which the first condition already rejects - so plain ordered compares are exact here.
-        const bool keep = (f_abs(determinant[hf]) >= 1e-4f) & (u[hf] >= 0.0f) & (u[hf] <= 1.0f) & (v[hf] >= 0.0f) &
-                          (uv[hf] <= 1.0f) & (dist[hf] > 0.0f);
+        // `u > 1.0` (mod.rs:579) needs no instruction of its own: with v >= 0, u <= RN(u+v) by monotonicity of
+        // rounding, so u > 1 implies (u+v) > 1, which is tested.
+        const bool keep = (f_abs(determinant[hf]) >= 1e-4f) & (u[hf] >= 0.0f) & (v[hf] >= 0.0f) & (uv[hf] <= 1.0f) &
+                          (dist[hf] > 0.0f);
         const int32_t id = (int32_t)tr.id[hf];
         const bool closer = ORDERED ? (dist[hf] < mt) : (dist[hf] < mt || (dist[hf] == mt && id < mid));
         if (keep & closer) {

@@ -49,6 +49,7 @@ PT_HD float dot(vec3 a, vec3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 PT_HD vec3 cross(vec3 a, vec3 b) {
     return mk(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
 }
+PT_HD float f_abs(float x) { return __builtin_fabsf(x); }
 // IEEE correctly rounded square root and reciprocal on both sides (x86: sqrtss / divss).
 // On the device these are hipcc's own correctly-rounded expansions (-fhip-fp32-correctly-rounded-divide-sqrt)
 // with the input-scaling steps taken out of the common path:
@@ -64,10 +65,9 @@ PT_HD vec3 cross(vec3 a, vec3 b) {
 // HIP's __fsqrt_rn / __frcp_rn are the 1-ulp native ops and are not usable (tests caught it).
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ float f_sqrt(float x) {
-    const uint32_t bits = __float_as_uint(x);
-    // 0 < |x| < 2^-96  <=>  (bits & 0x7fffffff) in [1, 0x0F800000)   (negative tiny inputs too: the native op
-    // flushes -denormal to -0 where IEEE wants NaN)
-    if (__builtin_amdgcn_ballot_w64(((bits & 0x7fffffffu) - 1u) < 0x0F7FFFFFu) != 0ull) return __builtin_sqrtf(x);
+    // |x| < 2^-96 (one compare with the |.| source modifier): tiny inputs of either sign - the native op flushes
+    // -denormal to -0 where IEEE wants NaN - and, harmlessly, +-0 take the full path; NaN does not
+    if (__builtin_amdgcn_ballot_w64(f_abs(x) < 0x1p-96f) != 0ull) return __builtin_sqrtf(x);
     const float s = __builtin_amdgcn_sqrtf(x);
     const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
     const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
@@ -88,7 +88,6 @@ __device__ __forceinline__ float f_rcp(float d) {
 PT_HD float f_sqrt(float x) { return __builtin_sqrtf(x); }
 PT_HD float f_rcp(float d) { return 1.0f / d; }
 #endif
-PT_HD float f_abs(float x) { return __builtin_fabsf(x); }
 PT_HD float f_max(float a, float b) { return __builtin_fmaxf(a, b); }
 PT_HD float length(vec3 a) { return f_sqrt(dot(a, a)); }
 PT_HD vec3 normalize(vec3 a) { return a * f_rcp(length(a)); }
