@@ -138,6 +138,12 @@ int pt_ctx_set_scene(pt_ctx *ctx, const pt_camera *cam, const pt_object *objs, u
 int pt_ctx_render(pt_ctx *ctx, const pt_config *cfg, void *d_out_rgb, void *hip_stream,
                   const volatile uint8_t *cancel, pt_progress_fn cb, void *user, pt_stats *stats);
 
+/* Device buffers for hosts that have no GPU allocator of their own (a Rust/C host driving pt_ctx_render;
+ * tests).  Plain hipMalloc / hipFree / hipMemcpy on `device`. */
+int pt_device_malloc(int device, size_t bytes, void **out);
+int pt_device_free(int device, void *p);
+int pt_device_download(int device, void *dst_host, const void *src_device, size_t bytes);
+
 /* Enable HIP-event timing of every intersect-kernel launch (fills pt_stats.ms_intersect). */
 int pt_ctx_set_profiling(pt_ctx *ctx, int enabled);
 
@@ -162,6 +168,28 @@ void pt_host_sincos(float y, float *s, float *c);
 int pt_render(const pt_config *cfg, const pt_camera *cam, const pt_object *objs, uint32_t n_objs,
               const pt_triangle *tris, uint32_t n_tris, float *out_rgb,
               const volatile uint8_t *cancel, pt_progress_fn cb, void *user, pt_stats *stats);
+
+/* The same frame cut into n_ranks contiguous bands, one host thread and one context per band, band r on device
+ * r mod pt_device_count(): single-process multi-GPU for hosts that want the image in HOST memory (the CLI).
+ * Each band is downloaded straight into its slice of out_rgb, so no device-to-device collective is involved;
+ * a host that keeps the framebuffer on the GPUs runs one process per GPU over pt_ctx_render and gathers the
+ * bands with RCCL (bench.py).  The image is bit-identical for every n_ranks. */
+int pt_render_multi(const pt_config *cfg, uint32_t n_ranks, const pt_camera *cam, const pt_object *objs,
+                    uint32_t n_objs, const pt_triangle *tris, uint32_t n_tris, float *out_rgb,
+                    const volatile uint8_t *cancel, pt_progress_fn cb, void *user, pt_stats *stats);
+
+/* Progressive preview (RenderUpdate, mod.rs:881-885, sent every 500 ms by mod.rs:965-982): callable from the
+ * progress callback of pt_ctx_render on the same thread.  Resolves what has been accumulated so far into
+ * d_out_rgb (band layout) and reports how many samples per pixel it holds.  The reference's snapshot is a
+ * random subset of finished pixels; this one is every pixel at partial spp. */
+int pt_ctx_snapshot(pt_ctx *ctx, void *d_out_rgb, uint32_t *spp_done);
+
+/* Image.hash (mod.rs:897-926): Rust's DefaultHasher (SipHash-1-3, zero key) over the f32 bit patterns of the
+ * pixels in order; the GUI uses it to invalidate its canvas cache (src/views/render_tab.rs:248-256). */
+uint64_t pt_image_hash(const float *rgb, size_t n_floats);
+/* the underlying SipHash-c-d (k0, k1 = key) so that the implementation can be pinned on the published
+ * SipHash-2-4 test vector */
+uint64_t pt_siphash(uint32_t c_rounds, uint32_t d_rounds, uint64_t k0, uint64_t k1, const uint8_t *data, size_t len);
 
 /* ---- formats either side of the path (host only, no GPU needed) ------------------------- */
 

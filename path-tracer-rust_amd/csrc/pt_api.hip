@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ptrace.h"
@@ -76,6 +77,9 @@ struct pt_ctx {
     DevBuf<uint32_t> q_meta[2], cnt, flags;
     DevBuf<unsigned long long> blk_rays, acc, total_rays;
     std::vector<hipEvent_t> ev_pool;
+    // state of the frame being rendered (for pt_ctx_snapshot from the progress callback)
+    uint32_t live_npix = 0, live_spp_issued = 0;
+    hipStream_t live_stream = nullptr;
 };
 
 namespace {
@@ -231,6 +235,7 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &F, hipS
         const uint32_t s0 = p * spp_pass;
         const uint32_t s_here = (cfg->spp - s0) < spp_pass ? (cfg->spp - s0) : spp_pass;
         launch_generate(st, K, F, queue_of(c, 0), c->cnt.p, cap, s0, s_here, m);
+        c->live_spp_issued = s0 + s_here;
         for (int d = 0; d < n_depth; ++d) {
             const RayQueue qin = queue_of(c, d & 1), qout = queue_of(c, (d + 1) & 1);
             if (c->profiling) {
@@ -480,6 +485,38 @@ int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uin
     return PT_OK;
 }
 
+int pt_device_malloc(int device, size_t bytes, void **out) {
+    if (!out) {
+        set_error("out is NULL");
+        return PT_ERR_INVALID;
+    }
+    *out = nullptr;
+    if (device_count_quiet() <= 0) {
+        set_error("no HIP device");
+        return PT_ERR_NO_DEVICE;
+    }
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMalloc(out, bytes ? bytes : 1));
+    return PT_OK;
+}
+
+int pt_device_free(int device, void *p) {
+    if (!p) return PT_OK;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipFree(p));
+    return PT_OK;
+}
+
+int pt_device_download(int device, void *dst_host, const void *src_device, size_t bytes) {
+    if (!dst_host || !src_device) {
+        set_error("NULL argument");
+        return PT_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemcpy(dst_host, src_device, bytes, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
 int pt_ctx_set_profiling(pt_ctx *c, int enabled) {
     if (!c) {
         set_error("ctx is NULL");
@@ -506,6 +543,9 @@ int pt_ctx_render(pt_ctx *c, const pt_config *cfg, void *d_out_rgb, void *hip_st
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     const FrameParams F = make_frame(c, cfg, ib, ie);
     if (stats) memset(stats, 0, sizeof *stats);
+    c->live_npix = F.npix;
+    c->live_spp_issued = 0;
+    c->live_stream = st;
     // PT_FLAG_NO_BVH: scan meshes triangle by triangle as the reference does (same result, for A/B checks)
     c->scene.n_bvh_nodes = (cfg->flags & PT_FLAG_NO_BVH) ? 0u : c->n_bvh_nodes;
     const double t0 = now_ms();
@@ -522,6 +562,7 @@ int pt_ctx_render(pt_ctx *c, const pt_config *cfg, void *d_out_rgb, void *hip_st
     }
     if (stats) stats->ms_total = now_ms() - t0;
     c->scene.n_bvh_nodes = c->n_bvh_nodes;
+    c->live_npix = 0;
     return rc;
 }
 
@@ -579,6 +620,24 @@ int pt_ctx_intersect(pt_ctx *c, const float *o, const float *d, uint32_t n, floa
 
 void pt_host_sincos(float y, float *s, float *c) { sincos_f32(y, s, c); }
 
+int pt_ctx_snapshot(pt_ctx *c, void *d_out_rgb, uint32_t *spp_done) {
+    if (!c || !d_out_rgb) {
+        set_error("NULL argument");
+        return PT_ERR_INVALID;
+    }
+    if (c->live_npix == 0 || c->live_spp_issued == 0) {
+        set_error("no frame in progress (call from the progress callback of pt_ctx_render)");
+        return PT_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    // stream order: the resolve runs after every pass issued so far, i.e. over live_spp_issued samples per pixel
+    launch_resolve(c->live_stream, c->acc.p, (float *)d_out_rgb, c->live_npix, c->live_spp_issued);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->live_stream));
+    if (spp_done) *spp_done = c->live_spp_issued;
+    return PT_OK;
+}
+
 int pt_ctx_numerics_probe(pt_ctx *c, const float *in, uint32_t n, float *out_sin, float *out_cos, float *out_sqrt,
                           float *out_rcp, uint32_t *out_philox) {
     if (!c || !in || !out_sin || !out_cos || !out_sqrt || !out_rcp || !out_philox || n == 0) {
@@ -616,6 +675,41 @@ int pt_ctx_numerics_probe(pt_ctx *c, const float *in, uint32_t n, float *out_sin
     return PT_OK;
 }
 
+// one band on one device into the host framebuffer
+static int render_band_to_host(int dev, const pt_config *cfg, const pt_camera *cam, const pt_object *objs,
+                               uint32_t n_objs, const pt_triangle *tris, uint32_t n_tris, float *out_rgb,
+                               const volatile uint8_t *cancel, pt_progress_fn cb, void *user, pt_stats *stats,
+                               std::string *err) {
+    uint32_t ib = 0, ie = 0;
+    int rc = check_cfg(cfg, &ib, &ie);
+    pt_ctx *c = nullptr;
+    if (!rc) rc = pt_ctx_create(dev, &c);
+    if (!rc) rc = pt_ctx_set_scene(c, cam, objs, n_objs, tris, n_tris);
+    float *d_out = nullptr;
+    const size_t nfl = (size_t)(ie - ib) * 3;
+    if (!rc) {
+        hipError_t e = hipMalloc((void **)&d_out, nfl * sizeof(float));
+        if (e != hipSuccess) {
+            set_error(std::string("hipMalloc(out): ") + hipGetErrorString(e));
+            rc = PT_ERR_HIP;
+        }
+    }
+    if (!rc) {
+        rc = pt_ctx_render(c, cfg, d_out, nullptr, cancel, cb, user, stats);
+        if (rc == PT_OK || rc == PT_CANCELLED) {
+            hipError_t e = hipMemcpy(out_rgb + (size_t)ib * 3, d_out, nfl * sizeof(float), hipMemcpyDeviceToHost);
+            if (e != hipSuccess) {
+                set_error(std::string("hipMemcpy(out): ") + hipGetErrorString(e));
+                rc = PT_ERR_HIP;
+            }
+        }
+    }
+    if (rc && err) *err = g_last_error;  // the message lives in this thread's slot
+    if (d_out) (void)hipFree(d_out);
+    if (c) pt_ctx_destroy(c);
+    return rc;
+}
+
 int pt_render(const pt_config *cfg, const pt_camera *cam, const pt_object *objs, uint32_t n_objs,
               const pt_triangle *tris, uint32_t n_tris, float *out_rgb, const volatile uint8_t *cancel,
               pt_progress_fn cb, void *user, pt_stats *stats) {
@@ -623,36 +717,64 @@ int pt_render(const pt_config *cfg, const pt_camera *cam, const pt_object *objs,
         set_error("out_rgb is NULL");
         return PT_ERR_INVALID;
     }
+    int dev = 0;
+    if (const char *e = getenv("PT_DEVICE")) dev = atoi(e);
+    return render_band_to_host(dev, cfg, cam, objs, n_objs, tris, n_tris, out_rgb, cancel, cb, user, stats, nullptr);
+}
+
+int pt_render_multi(const pt_config *cfg, uint32_t n_ranks, const pt_camera *cam, const pt_object *objs,
+                    uint32_t n_objs, const pt_triangle *tris, uint32_t n_tris, float *out_rgb,
+                    const volatile uint8_t *cancel, pt_progress_fn cb, void *user, pt_stats *stats) {
+    if (!out_rgb || n_ranks == 0 || n_ranks > 64) {
+        set_error("out_rgb is NULL or n_ranks outside 1..64");
+        return PT_ERR_INVALID;
+    }
     uint32_t ib = 0, ie = 0;
     int rc = check_cfg(cfg, &ib, &ie);
     if (rc) return rc;
-    int dev = 0;
-    if (const char *e = getenv("PT_DEVICE")) dev = atoi(e);
-    pt_ctx *c = nullptr;
-    if ((rc = pt_ctx_create(dev, &c))) return rc;
-    if ((rc = pt_ctx_set_scene(c, cam, objs, n_objs, tris, n_tris))) {
-        pt_ctx_destroy(c);
-        return rc;
+    const int n_dev = device_count_quiet();
+    if (n_dev <= 0) {
+        set_error("no HIP device: libptrace_hip has no CPU fallback");
+        return PT_ERR_NO_DEVICE;
     }
-    const size_t nfl = (size_t)(ie - ib) * 3;
-    float *d_out = nullptr;
-    hipError_t e = hipMalloc((void **)&d_out, nfl * sizeof(float));
-    if (e != hipSuccess) {
-        set_error(std::string("hipMalloc(out): ") + hipGetErrorString(e));
-        pt_ctx_destroy(c);
-        return PT_ERR_HIP;
+    // rank r renders the r-th contiguous slice of [ib, ie) on device r mod n_dev; pixels are independent and the
+    // RNG is keyed on the global pixel index, so the image does not depend on n_ranks (mod.rs:1021-1023)
+    const uint64_t span = ie - ib;
+    std::vector<pt_config> cfgs(n_ranks, *cfg);
+    std::vector<pt_stats> sts(n_ranks);
+    std::vector<int> rcs(n_ranks, PT_OK);
+    std::vector<std::string> errs(n_ranks);
+    std::vector<std::thread> th;
+    const double t0 = now_ms();
+    for (uint32_t r = 0; r < n_ranks; ++r) {
+        cfgs[r].idx_begin = ib + (uint32_t)(span * r / n_ranks);
+        cfgs[r].idx_end = ib + (uint32_t)(span * (r + 1) / n_ranks);
+        if (cfgs[r].idx_begin == cfgs[r].idx_end) continue;  // more ranks than pixels
+        th.emplace_back([&, r]() {
+            rcs[r] = render_band_to_host((int)(r % (uint32_t)n_dev), &cfgs[r], cam, objs, n_objs, tris, n_tris, out_rgb,
+                                         cancel, r == 0 ? cb : nullptr, user, &sts[r], &errs[r]);
+        });
     }
-    rc = pt_ctx_render(c, cfg, d_out, nullptr, cancel, cb, user, stats);
-    if (rc == PT_OK || rc == PT_CANCELLED) {
-        e = hipMemcpy(out_rgb + (size_t)ib * 3, d_out, nfl * sizeof(float), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) {
-            set_error(std::string("hipMemcpy(out): ") + hipGetErrorString(e));
-            rc = PT_ERR_HIP;
+    for (auto &t : th) t.join();
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        for (uint32_t r = 0; r < n_ranks; ++r) {
+            stats->ray_bounces += sts[r].ray_bounces;
+            stats->samples += sts[r].samples;
+            stats->intersect_rays += sts[r].intersect_rays;
+            stats->intersect_launches += sts[r].intersect_launches;
+            stats->passes += sts[r].passes;
+            stats->ms_device = sts[r].ms_device > stats->ms_device ? sts[r].ms_device : stats->ms_device;
+            stats->ms_intersect += sts[r].ms_intersect;
         }
+        stats->ms_total = now_ms() - t0;
     }
-    (void)hipFree(d_out);
-    pt_ctx_destroy(c);
-    return rc;
+    for (uint32_t r = 0; r < n_ranks; ++r)
+        if (rcs[r] != PT_OK) {
+            set_error("rank " + std::to_string(r) + ": " + errs[r]);
+            return rcs[r];
+        }
+    return PT_OK;
 }
 
 }  // extern "C"

@@ -20,7 +20,7 @@
 static void usage() {
     fprintf(stderr,
             "usage: ptrace <samplesPerPixel> <y-resolution> <scene id|index> [--width W] [--backend wavefront|megakernel]\n"
-            "              [--seed S] [--root DIR] [--out DIR] [--no-ppm]\n");
+            "              [--seed S] [--gpus N] [--root DIR] [--out DIR] [--no-ppm]\n");
 }
 
 static std::vector<std::string> scene_ids(const std::string &root) {
@@ -52,12 +52,14 @@ int main(int argc, char **argv) {
     uint32_t width = res_y * 3 / 2;
     uint64_t seed = (uint64_t)time(nullptr);
     bool write_ppm = true;
+    uint32_t gpus = 1;
     for (int i = 4; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() -> const char * { return i + 1 < argc ? argv[++i] : ""; };
         if (a == "--width") width = (uint32_t)strtoul(next(), nullptr, 10);
         else if (a == "--backend") backend = next();
         else if (a == "--seed") seed = strtoull(next(), nullptr, 10);
+        else if (a == "--gpus") gpus = (uint32_t)strtoul(next(), nullptr, 10);
         else if (a == "--root") root = next();
         else if (a == "--out") out_dir = next();
         else if (a == "--no-ppm") write_ppm = false;
@@ -102,7 +104,8 @@ int main(int argc, char **argv) {
     cfg.seed = seed;
     std::vector<float> img((size_t)width * res_y * 3, 0.0f);
     pt_stats st;
-    rc = pt_render(&cfg, pt_scene_camera(sc), objs, n_objs, tris, n_tris, img.data(), nullptr, progress, nullptr, &st);
+    rc = pt_render_multi(&cfg, gpus ? gpus : 1, pt_scene_camera(sc), objs, n_objs, tris, n_tris, img.data(), nullptr,
+                         progress, nullptr, &st);
     fprintf(stderr, "\n");
     if (rc) {
         fprintf(stderr, "render failed (%d): %s\n", rc, pt_last_error());

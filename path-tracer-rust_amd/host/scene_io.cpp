@@ -547,6 +547,42 @@ const pt_triangle *pt_scene_triangles(const pt_scene *s, uint32_t *n) {
     return s ? s->triangles.data() : nullptr;
 }
 
+// SipHash-c-d (Aumasson & Bernstein), little-endian message words, 64-bit tag
+uint64_t pt_siphash(uint32_t c_rounds, uint32_t d_rounds, uint64_t k0, uint64_t k1, const uint8_t *data, size_t len) {
+    uint64_t s0 = k0 ^ 0x736f6d6570736575ull, s1 = k1 ^ 0x646f72616e646f6dull;
+    uint64_t s2 = k0 ^ 0x6c7967656e657261ull, s3 = k1 ^ 0x7465646279746573ull;
+    auto rotl = [](uint64_t x, int b) { return (x << b) | (x >> (64 - b)); };
+    auto round = [&]() {
+        s0 += s1, s2 += s3;
+        s1 = rotl(s1, 13) ^ s0, s3 = rotl(s3, 16) ^ s2;
+        s0 = rotl(s0, 32);
+        s2 += s1, s0 += s3;
+        s1 = rotl(s1, 17) ^ s2, s3 = rotl(s3, 21) ^ s0;
+        s2 = rotl(s2, 32);
+    };
+    const size_t whole = len / 8;
+    for (size_t w = 0; w < whole; ++w) {
+        uint64_t mword = 0;
+        for (int k = 7; k >= 0; --k) mword = (mword << 8) | data[8 * w + (size_t)k];
+        s3 ^= mword;
+        for (uint32_t r = 0; r < c_rounds; ++r) round();
+        s0 ^= mword;
+    }
+    uint64_t last = (uint64_t)(len & 0xff) << 56;
+    for (size_t k = 0; k < (len & 7); ++k) last |= (uint64_t)data[8 * whole + k] << (8 * k);
+    s3 ^= last;
+    for (uint32_t r = 0; r < c_rounds; ++r) round();
+    s0 ^= last;
+    s2 ^= 0xff;
+    for (uint32_t r = 0; r < d_rounds; ++r) round();
+    return s0 ^ s1 ^ s2 ^ s3;
+}
+
+uint64_t pt_image_hash(const float *rgb, size_t n_floats) {
+    // v.x.to_bits().hash(..) for every component in order == the byte stream of the f32 array (mod.rs:919-923)
+    return pt_siphash(1, 3, 0, 0, reinterpret_cast<const uint8_t *>(rgb), n_floats * sizeof(float));
+}
+
 float pt_gamma_correction(float x) {
     const float c = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);  // f32::clamp keeps NaN
     return powf(c, 1.0f / 2.2f);

@@ -159,6 +159,17 @@ def product():
     L.pt_ctx_render.argtypes = [C.c_void_p, C.POINTER(PtConfig), C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.POINTER(PtStats)]
     L.pt_ctx_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.pt_render_multi.argtypes = [C.POINTER(PtConfig), C.c_uint32, C.POINTER(PtCamera), C.POINTER(PtObject), C.c_uint32,
+                                  C.POINTER(PtTriangle), C.c_uint32, fp, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.POINTER(PtStats)]
+    L.pt_ctx_snapshot.argtypes = [C.c_void_p, C.c_void_p, u32p]
+    L.pt_device_malloc.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
+    L.pt_device_free.argtypes = [C.c_int, C.c_void_p]
+    L.pt_device_download.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.pt_image_hash.argtypes = [fp, C.c_size_t]
+    L.pt_image_hash.restype = C.c_uint64
+    L.pt_siphash.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_char_p, C.c_size_t]
+    L.pt_siphash.restype = C.c_uint64
     L.pt_host_sincos.argtypes = [C.c_float, fp, fp]
     L.pt_host_sincos.restype = None
     L.pt_ctx_numerics_probe.argtypes = [C.c_void_p, fp, C.c_uint32, fp, fp, fp, fp, u32p]

@@ -141,3 +141,18 @@ def test_product_sincos_equals_oracle_on_whole_domain():
                                "-Wl,-rpath," + os.path.dirname(ptlib.ORACLE_SO), "-lm"])
         out = subprocess.check_output([exe]).decode().strip()
     assert out == "0"
+
+
+def test_siphash_pinned_and_image_hash():
+    """SipHash-2-4 official test vector (key 00..0f, message 00..0e -> a129ca6149be45e5) pins the implementation;
+    Image.hash is the same code with 1 and 3 rounds and a zero key (Rust DefaultHasher).  The oracle's separate
+    SipHash-1-3 agrees."""
+    key = bytes(range(16))
+    k0, k1 = int.from_bytes(key[:8], "little"), int.from_bytes(key[8:], "little")
+    assert L.pt_siphash(2, 4, k0, k1, bytes(range(15)), 15) == 0xa129ca6149be45e5
+    assert L.pt_siphash(2, 4, k0, k1, b"", 0) == 0x726fdb47dd0e0e31
+    rng = np.random.default_rng(2)
+    for n in (0, 1, 2, 3, 7, 24, 1000):
+        img = rng.uniform(0, 1, size=n).astype(np.float32)
+        assert L.pt_image_hash(_np_f(img), n) == O.pto_image_hash(_np_f(img), n)
+        assert L.pt_image_hash(_np_f(img), n) == L.pt_siphash(1, 3, 0, 0, img.tobytes(), 4 * n)

@@ -336,3 +336,50 @@ def test_full_size_mesh_bvh_vs_scan(gpu):
     assert res[0][1] == res[1][1]
     assert np.array_equal(res[0][0], res[1][0])
     assert 7.0 < res[0][1] / (w * h * spp) < 8.2  # 7.4-7.7 bounces per sample (survey probe / oracle)
+
+
+def test_render_multi_and_snapshot(gpu):
+    """pt_render_multi with 1, 3 and 5 bands (all on this box's one GPU) == pt_render, bit for bit; the progress
+    callback can pull partial frames with pt_ctx_snapshot and the last one (all spp) equals the final image."""
+    L, ctx = gpu
+    sc = ptlib.load_scene_py(ptlib.scene_path("cornell"))
+    w, h, spp = 64, 40, 12
+    whole, st = gpu_render(gpu, sc, w, h, spp, 8)
+    for n in (1, 3, 5):
+        cfg = PtConfig(w, h, spp, 0, 8, 0, 0, 0, 0)
+        out = np.zeros((w * h, 3), dtype=np.float32)
+        s2 = PtStats()
+        rc = L.pt_render_multi(C.byref(cfg), n, C.byref(sc.cam), sc.objs, sc.n_objs, sc.tris, sc.n_tris, _np_f(out),
+                               None, None, None, C.byref(s2))
+        assert rc == 0, L.pt_last_error()
+        assert np.array_equal(out, whole) and s2.ray_bounces == st.ray_bounces
+    # snapshots: 12 passes of 1 spp; the callback fires between passes
+    set_scene(gpu, sc)
+    nbytes = w * h * 3 * 4
+    d_out, d_snap = C.c_void_p(), C.c_void_p()
+    assert L.pt_device_malloc(0, nbytes, C.byref(d_out)) == 0 and L.pt_device_malloc(0, nbytes, C.byref(d_snap)) == 0
+
+    def download(ptr):
+        host = np.zeros((w * h, 3), dtype=np.float32)
+        assert L.pt_device_download(0, host.ctypes.data_as(C.c_void_p), ptr, nbytes) == 0
+        return host
+
+    seen = []
+
+    def on_progress(user, frac):
+        n = C.c_uint32()
+        if L.pt_ctx_snapshot(ctx, d_snap, C.byref(n)) == 0:
+            seen.append((frac, n.value, download(d_snap)))
+
+    cb = ptlib.PROGRESS_FN(on_progress)
+    cfg = PtConfig(w, h, spp, 0, 8, 0, 0, 1, 0)
+    s3 = PtStats()
+    rc = L.pt_ctx_render(ctx, C.byref(cfg), d_out, None, None, C.cast(cb, C.c_void_p), None, C.byref(s3))
+    assert rc == 0, L.pt_last_error()
+    assert np.array_equal(download(d_out), whole)
+    assert len(seen) >= 3 and all(1 <= n <= spp for _, n, _ in seen)
+    # a snapshot over k samples is the k-spp frame of the same seed (sample indices 0..k-1)
+    frac, k, img = seen[1]
+    ref, _ = gpu_render(gpu, sc, w, h, k, 8)
+    assert np.array_equal(img, ref)
+    assert L.pt_device_free(0, d_out) == 0 and L.pt_device_free(0, d_snap) == 0
