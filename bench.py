@@ -194,6 +194,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": None,
+            "algorithmic_bytes_per_launch": INTERSECT_BYTES_PER_RAY * main_run["isect_rays"] / max(1, main_run["launches"]),
             "bytes_per_ray": INTERSECT_BYTES_PER_RAY,
             "rays_per_launch": main_run["isect_rays"] / max(1, main_run["launches"]),
             "avg_launch_ms": main_run["isect_ms"] / max(1, main_run["launches"]),
@@ -205,7 +206,10 @@ def main():
             try:
                 with open(prof) as f:
                     tr = json.load(f)
-                out["roofline"]["traffic"] = tr.get("hbm_bytes_per_launch")
+                # PMC bytes per ray (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate rocprofv3 passes of this
+                # command at reduced spp, committed under profiles/) times the rays one launch processes
+                out["roofline"]["traffic"] = tr["hbm_bytes_per_ray"] * out["roofline"]["rays_per_launch"]
+                out["roofline"]["traffic_bytes_per_ray"] = tr["hbm_bytes_per_ray"]
                 out["roofline"]["traffic_source"] = tr.get("source")
             except Exception:
                 pass
