@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libptrace_hip.so")
+LIB_PATH = os.environ.get("PT_LIB") or os.path.join(_HERE, "libptrace_hip.so")  # PT_LIB: A/B builds when tuning
 
 f3 = C.c_float * 3
 

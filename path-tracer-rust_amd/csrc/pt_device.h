@@ -125,6 +125,13 @@ struct FrameParams {
     uint32_t debug;                // ablation switches for profiling builds (PT_DEBUG env): 0 in production
 };
 
+// the part of FrameParams the shading step needs (keeps k_shade's kernel arguments - SGPRs - small)
+struct ShadeParams {
+    uint32_t idx_begin, npix;
+    uint32_t seed_lo, seed_hi;
+    uint32_t debug;
+};
+
 // ray meta word: sample index (24 bits) | depth (4 bits) | branch id (3 bits)
 PT_HD uint32_t pack_meta(uint32_t sample, uint32_t depth, uint32_t branch) {
     return (sample & 0xFFFFFFu) | (depth << 24) | (branch << 28);
@@ -428,7 +435,8 @@ __device__ __forceinline__ Surface fetch_surface(const DevScene &S, vec3 o, vec3
 }
 
 // One radiance() invocation after its intersect_scene call returned Some (mod.rs:665-789).
-__device__ __forceinline__ void shade_hit(const DevScene &S, const FrameParams &F, const PathRay &in, HitRec h,
+template <class Params>
+__device__ __forceinline__ void shade_hit(const DevScene &S, const Params &F, const PathRay &in, HitRec h,
                                           ShadeOut &out) {
     const Surface sf = fetch_surface(S, in.o, in.d, h);
     const vec3 d = in.d;

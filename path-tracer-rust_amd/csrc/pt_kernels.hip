@@ -87,7 +87,7 @@ __device__ __forceinline__ void add_radiance_lds(unsigned long long *lds_acc, ui
     if (bl) atomicAdd(&lds_acc[2u * m + slot], (unsigned long long)bl);
 }
 
-__global__ __launch_bounds__(kBlock) void k_shade(DevScene S, FrameParams F, RayQueue qin, RayQueue qout,
+__global__ __launch_bounds__(kBlock) void k_shade(DevScene S, ShadeParams F, RayQueue qin, RayQueue qout,
                                                   const float2 *__restrict__ hit,
                                                   const uint32_t *__restrict__ cnt_in,
                                                   uint32_t *__restrict__ cnt_out, uint32_t cap,
@@ -375,7 +375,13 @@ void launch_shade(hipStream_t st, uint32_t K, const DevScene &S, const FramePara
                   const RayQueue &qout, const float2 *hit, const uint32_t *cnt_in, uint32_t *cnt_out, uint32_t cap,
                   unsigned long long *acc, uint32_t *flags, uint32_t m) {
     const size_t lds = (size_t)3 * m * sizeof(unsigned long long) + 16;
-    hipLaunchKernelGGL(k_shade, dim3(K), dim3(kBlock), lds, st, S, F, qin, qout, hit, cnt_in, cnt_out, cap, acc,
+    ShadeParams P;
+    P.idx_begin = F.idx_begin;
+    P.npix = F.npix;
+    P.seed_lo = F.seed_lo;
+    P.seed_hi = F.seed_hi;
+    P.debug = F.debug;
+    hipLaunchKernelGGL(k_shade, dim3(K), dim3(kBlock), lds, st, S, P, qin, qout, hit, cnt_in, cnt_out, cap, acc,
                        flags, m);
 }
 void launch_resolve(hipStream_t st, const unsigned long long *acc, float *out, uint32_t npix, uint32_t spp) {

@@ -383,3 +383,60 @@ def test_render_multi_and_snapshot(gpu):
     ref, _ = gpu_render(gpu, sc, w, h, k, 8)
     assert np.array_equal(img, ref)
     assert L.pt_device_free(0, d_out) == 0 and L.pt_device_free(0, d_snap) == 0
+
+
+def test_edge_scenes(gpu):
+    """Edge cases the domain has: an empty scene (every ray misses), a 1x1 frame, a scene made only of meshes,
+    degenerate (zero-area) and tiny triangles (|det| < 1e-4 rejects them, mod.rs:571), a black object
+    (max_reflection = 0: roulette always stops, 1/0 = inf never used), a sphere the camera sits inside."""
+    cam = ptlib.make_camera((0, 0, 5), (0, 0, -1))
+    cases = {
+        "empty": ptlib.Scene("e", cam, [], []),
+        "only_meshes": ptlib.Scene("m", cam, [
+            ptlib.make_mesh((0, 0, 0), (0.8, 0.8, 0.8), (0.5, 0.5, 0.5), "Diffuse", 0, 3, (0, 0, 0), 10.0)],
+            [ptlib.make_tri((-1, -1, 0), (1, -1, 0), (0, 1, 0)),
+             ptlib.make_tri((0, 0, 1), (0, 0, 1), (0, 0, 1)),                 # zero area
+             ptlib.make_tri((0, 0, 2), (1e-3, 0, 2), (0, 1e-3, 2))]),         # tiny: det below 1e-4
+        "black_and_inside": ptlib.Scene("b", cam, [
+            ptlib.make_sphere((0, 0, 5), 30.0, (0.0, 0.0, 0.0), (0.3, 0.2, 0.1), "Diffuse"),   # camera inside, black
+            ptlib.make_sphere((0, 0, 0), 1.0, (0.9, 0.9, 0.9), (0, 0, 0), "Refract"),
+            ptlib.make_sphere((2, 0, 0), 1.0, (0.9, 0.9, 0.9), (0, 0, 0), "Specular")], []),
+    }
+    for name, sc in cases.items():
+        for (w, h, spp) in ((1, 1, 5), (33, 17, 6)):
+            want, cnt, _ = ptlib.oracle_render(sc, w, h, spp, 21)
+            for backend in (0, 1):
+                got, st = gpu_render(gpu, sc, w, h, spp, 21, backend)
+                assert st.ray_bounces == cnt.ray_bounces, (name, backend)
+                assert float(np.abs(got - want).max()) <= TOL, (name, backend)
+    # malformed scenes are rejected, not rendered
+    L, ctx = gpu
+    bad = ptlib.Scene("x", cam, [ptlib.make_mesh((0, 0, 0), (1, 1, 1), (0, 0, 0), "Diffuse", 0, 5, (0, 0, 0), 1.0)],
+                      [ptlib.make_tri((0, 0, 0), (1, 0, 0), (0, 1, 0))])
+    assert L.pt_ctx_set_scene(ctx, C.byref(bad.cam), bad.objs, bad.n_objs, bad.tris, bad.n_tris) == -1
+    o = ptlib.make_sphere((0, 0, 0), 1.0, (1, 1, 1), (0, 0, 0), "Diffuse")
+    o.reflect_type = 9
+    bad = ptlib.Scene("y", cam, [o], [])
+    assert L.pt_ctx_set_scene(ctx, C.byref(bad.cam), bad.objs, bad.n_objs, bad.tris, bad.n_tris) == -1
+
+
+def test_largest_frame_geometry(gpu):
+    """BASELINE config 5 geometry (cornell 4096x4096) at 2 spp: 16.7 M pixels, 16 384 streams of 1 024 pixels,
+    33 M primary rays in one pass.  Wavefront == megakernel bit for bit, bounce counts equal, and a sample of
+    pixels agrees with the oracle."""
+    O = ptlib.oracle()
+    sc = ptlib.load_scene_py(ptlib.scene_path("cornell"))
+    w = h = 4096
+    spp = 2
+    a, sa = gpu_render(gpu, sc, w, h, spp, 1, 0)
+    b, sb = gpu_render(gpu, sc, w, h, spp, 1, 1)
+    assert sa.ray_bounces == sb.ray_bounces and sa.samples == w * h * spp
+    assert np.array_equal(a, b)
+    ps = sc.pto()
+    cfg = PtoConfig(w, h, spp, 0, 1)
+    rng = np.random.default_rng(9)
+    px = np.zeros(3, np.float32)
+    idxs = list(rng.integers(0, w * h, size=400)) + [0, w * h - 1, w * h // 2, 1024 * 1024 - 1, 1024 * 1024]
+    for idx in idxs:
+        O.pto_render_pixel(C.byref(ps), C.byref(cfg), int(idx), _np_f(px), None)
+        assert float(np.abs(px - a[idx]).max()) <= TOL, idx
