@@ -199,6 +199,11 @@ typedef struct pt_scene pt_scene;
  * `path` is the JSON file; MeshFile paths are resolved against `base_dir` (the reference
  * resolves them against the process CWD; pass "." for that behaviour). */
 int pt_scene_load(const char *path, const char *base_dir, pt_scene **out);
+/* SceneData::to_descriptor + SceneDescriptor::save (mod.rs:112-117, 127-149): the same bytes
+ * serde_json::to_string_pretty writes (MeshFile objects keep their path/scale, inline meshes their
+ * bounding_sphere / bounding_box). */
+int pt_scene_save(const pt_scene *s, const char *path);
+int pt_scene_set_camera(pt_scene *s, const pt_camera *cam);
 void pt_scene_free(pt_scene *s);
 const char *pt_scene_id(const pt_scene *s);
 const pt_camera *pt_scene_camera(const pt_scene *s);

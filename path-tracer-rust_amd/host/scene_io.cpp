@@ -7,6 +7,7 @@
 //   pt_gamma_*      gamma_correction / to_int_with_...    src/render/mod.rs:57-63
 //
 // Where the reference panics (unwrap) this code returns PT_ERR_PARSE / PT_ERR_IO with a message.
+#include <algorithm>
 #include <cerrno>
 #include <cmath>
 #include <cstdio>
@@ -363,12 +364,165 @@ int load_off_impl(const std::string &path, float scale, std::vector<pt_triangle>
 
 }  // namespace
 
+// what SceneObjectDescriptorType keeps beyond the flattened object (needed to save the scene again)
+struct ObjDesc {
+    int variant = 0;  // 0 Sphere, 1 MeshFile, 2 Mesh
+    std::string path;
+    float scale = 0.0f;
+    std::vector<pt_triangle> bounding_box;  // Mesh.bounding_box as loaded (12 triangles; unused by the tracer)
+};
+
 struct pt_scene {
     std::string id;
     pt_camera camera{};
     std::vector<pt_object> objects;
     std::vector<pt_triangle> triangles;
+    std::vector<ObjDesc> desc;
 };
+
+namespace {
+
+// f32 -> text exactly as serde_json does (ryu's shortest round-trip digits, `format32` layout)
+std::string fmt_f32(float v) {
+    if (!std::isfinite(v)) return "null";
+    char buf[64];
+    int prec = 0;
+    for (; prec < 9; ++prec) {
+        snprintf(buf, sizeof buf, "%.*e", prec, (double)v);
+        if (strtof(buf, nullptr) == v) break;
+    }
+    snprintf(buf, sizeof buf, "%.*e", prec, (double)v);
+    // buf = [-]d[.ddd]e[+-]xx
+    std::string t = buf;
+    const bool neg = t[0] == '-';
+    if (neg) t.erase(0, 1);
+    const size_t epos = t.find('e');
+    std::string digits = t.substr(0, epos);
+    const int e10 = atoi(t.c_str() + epos + 1);
+    digits.erase(std::remove(digits.begin(), digits.end(), '.'), digits.end());
+    while (digits.size() > 1 && digits.back() == '0') digits.pop_back();
+    if (v == 0.0f) digits = "0";
+    const int len = (int)digits.size();
+    const int kk = e10 + 1;       // position of the decimal point relative to the first digit
+    const int k = kk - len;       // exponent of the last digit
+    std::string out;
+    if (0 <= k && kk <= 13) {
+        out = digits + std::string((size_t)k, '0') + ".0";
+    } else if (0 < kk && kk <= 13) {
+        out = digits.substr(0, (size_t)kk) + "." + digits.substr((size_t)kk);
+    } else if (-6 < kk && kk <= 0) {
+        out = "0." + std::string((size_t)(-kk), '0') + digits;
+    } else if (len == 1) {
+        out = digits + "e" + std::to_string(kk - 1);
+    } else {
+        out = digits.substr(0, 1) + "." + digits.substr(1) + "e" + std::to_string(kk - 1);
+    }
+    return neg ? "-" + out : out;
+}
+
+std::string json_escape(const std::string &in) {
+    std::string o = "\"";
+    for (unsigned char ch : in) {
+        switch (ch) {
+            case '"': o += "\\\""; break;
+            case '\\': o += "\\\\"; break;
+            case '\n': o += "\\n"; break;
+            case '\r': o += "\\r"; break;
+            case '\t': o += "\\t"; break;
+            case '\b': o += "\\b"; break;
+            case '\f': o += "\\f"; break;
+            default:
+                if (ch < 0x20) {
+                    char b[8];
+                    snprintf(b, sizeof b, "\\u%04x", ch);
+                    o += b;
+                } else {
+                    o += (char)ch;
+                }
+        }
+    }
+    return o + "\"";
+}
+
+// serde_json::to_string_pretty layout: 2-space indent, one array element per line
+struct Pretty {
+    std::string out;
+    int depth = 0;
+    void nl() {
+        out += '\n';
+        out.append((size_t)depth * 2, ' ');
+    }
+    void vec3(const float v[3]) {
+        out += '[';
+        ++depth;
+        for (int i = 0; i < 3; ++i) {
+            nl();
+            out += fmt_f32(v[i]);
+            if (i < 2) out += ',';
+        }
+        --depth;
+        nl();
+        out += ']';
+    }
+    void key(const char *k) {
+        nl();
+        out += '"';
+        out += k;
+        out += "\": ";
+    }
+    void triangles(const pt_triangle *t, size_t n) {
+        if (n == 0) {
+            out += "[]";
+            return;
+        }
+        out += '[';
+        ++depth;
+        for (size_t i = 0; i < n; ++i) {
+            nl();
+            out += '{';
+            ++depth;
+            key("a");
+            vec3(t[i].a);
+            out += ',';
+            key("b");
+            vec3(t[i].b);
+            out += ',';
+            key("c");
+            vec3(t[i].c);
+            --depth;
+            nl();
+            out += '}';
+            if (i + 1 < n) out += ',';
+        }
+        --depth;
+        nl();
+        out += ']';
+    }
+};
+
+// bounding_box_to_triangles (mod.rs:501-536) over the AABB of a triangle list, for meshes built through the API
+std::vector<pt_triangle> box_triangles(const pt_triangle *t, size_t n) {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t i = 0; i < n; ++i)
+        for (const float *v : {t[i].a, t[i].b, t[i].c})
+            for (int c = 0; c < 3; ++c) {
+                if (v[c] < lo[c]) lo[c] = v[c];
+                if (v[c] > hi[c]) hi[c] = v[c];
+            }
+    const float vx[8][3] = {{lo[0], lo[1], lo[2]}, {hi[0], lo[1], lo[2]}, {hi[0], hi[1], lo[2]}, {lo[0], hi[1], lo[2]},
+                            {lo[0], lo[1], hi[2]}, {hi[0], lo[1], hi[2]}, {hi[0], hi[1], hi[2]}, {lo[0], hi[1], hi[2]}};
+    const int idx[12][3] = {{0, 1, 2}, {0, 2, 3}, {4, 6, 5}, {4, 7, 6}, {0, 4, 5}, {0, 5, 1},
+                            {3, 2, 6}, {3, 6, 7}, {1, 5, 6}, {1, 6, 2}, {0, 3, 7}, {0, 7, 4}};
+    std::vector<pt_triangle> out(12);
+    for (int k = 0; k < 12; ++k) {
+        memcpy(out[(size_t)k].a, vx[idx[k][0]], 12);
+        memcpy(out[(size_t)k].b, vx[idx[k][1]], 12);
+        memcpy(out[(size_t)k].c, vx[idx[k][2]], 12);
+    }
+    return out;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -445,6 +599,7 @@ int pt_scene_load(const char *path, const char *base_dir, pt_scene **out) {
         const std::string where = "objects[" + std::to_string(i) + "]";
         pt_object o;
         memset(&o, 0, sizeof o);
+        ObjDesc od;
         const JValue *jt = jo.get("type_"), *jm = jo.get("material");
         if (jo.kind != JValue::Obj || !jt || !jm || jm->kind != JValue::Obj ||
             !get_vec3(c, jo.get("position"), "position", o.position) ||
@@ -480,12 +635,15 @@ int pt_scene_load(const char *path, const char *base_dir, pt_scene **out) {
             }
         } else if (tag == "MeshFile") {
             o.kind = PT_MESH;
+            od.variant = 1;
             const JValue *jp_ = body.get("path");
             float scale = 0.0f;
             if (!jp_ || jp_->kind != JValue::Str || !get_f32(c, body.get("scale"), "MeshFile.scale", &scale)) {
                 pt::set_error("scene: " + where + ": MeshFile needs `path` and `scale`");
                 return PT_ERR_PARSE;
             }
+            od.path = jp_->str;
+            od.scale = scale;
             std::vector<pt_triangle> tl;
             std::string err;
             const std::string full = (jp_->str.size() && jp_->str[0] == '/') ? jp_->str : base + "/" + jp_->str;
@@ -514,6 +672,16 @@ int pt_scene_load(const char *path, const char *base_dir, pt_scene **out) {
                               (c.err.empty() ? "" : " (" + c.err + ")"));
                 return PT_ERR_PARSE;
             }
+            od.variant = 2;
+            for (const auto &jb : jbb->arr) {
+                pt_triangle t;
+                if (jb->kind != JValue::Obj || !get_vec3(c, jb->get("a"), "bounding_box.a", t.a) ||
+                    !get_vec3(c, jb->get("b"), "bounding_box.b", t.b) || !get_vec3(c, jb->get("c"), "bounding_box.c", t.c)) {
+                    pt::set_error("scene: " + where + ": " + (c.err.empty() ? "bad bounding_box triangle" : c.err));
+                    return PT_ERR_PARSE;
+                }
+                od.bounding_box.push_back(t);
+            }
             o.tri_offset = (uint32_t)sc->triangles.size();
             o.tri_count = (uint32_t)jtri->arr.size();
             for (const auto &jtv : jtri->arr) {
@@ -530,8 +698,159 @@ int pt_scene_load(const char *path, const char *base_dir, pt_scene **out) {
             return PT_ERR_PARSE;
         }
         sc->objects.push_back(o);
+        sc->desc.push_back(od);
     }
     *out = sc.release();
+    return PT_OK;
+}
+
+// SceneData::to_descriptor + SceneDescriptor::save (mod.rs:112-117, 127-149): serde_json::to_string_pretty
+int pt_scene_save(const pt_scene *s, const char *path) {
+    if (!s || !path) {
+        pt::set_error("NULL argument");
+        return PT_ERR_INVALID;
+    }
+    Pretty w;
+    w.out += '{';
+    ++w.depth;
+    w.key("id");
+    w.out += json_escape(s->id);
+    w.out += ',';
+    w.key("objects");
+    if (s->objects.empty()) {
+        w.out += "[]";
+    } else {
+        w.out += '[';
+        ++w.depth;
+        for (size_t i = 0; i < s->objects.size(); ++i) {
+            const pt_object &o = s->objects[i];
+            const ObjDesc &d = s->desc[i];
+            w.nl();
+            w.out += '{';
+            ++w.depth;
+            w.key("type_");
+            w.out += '{';
+            ++w.depth;
+            if (d.variant == 0) {
+                w.key("Sphere");
+                w.out += '{';
+                ++w.depth;
+                w.key("radius");
+                w.out += fmt_f32(o.radius);
+                --w.depth;
+                w.nl();
+                w.out += '}';
+            } else if (d.variant == 1) {
+                w.key("MeshFile");
+                w.out += '{';
+                ++w.depth;
+                w.key("path");
+                w.out += json_escape(d.path);
+                w.out += ',';
+                w.key("scale");
+                w.out += fmt_f32(d.scale);
+                --w.depth;
+                w.nl();
+                w.out += '}';
+            } else {
+                w.key("Mesh");
+                w.out += '{';
+                ++w.depth;
+                w.key("triangles");
+                w.triangles(s->triangles.data() + o.tri_offset, o.tri_count);
+                w.out += ',';
+                w.key("bounding_sphere");
+                w.out += '{';
+                ++w.depth;
+                w.key("position");
+                w.vec3(o.bs_center);
+                w.out += ',';
+                w.key("radius");
+                w.out += fmt_f32(o.bs_radius);
+                --w.depth;
+                w.nl();
+                w.out += "},";
+                w.key("bounding_box");
+                const std::vector<pt_triangle> box =
+                    d.bounding_box.empty() ? box_triangles(s->triangles.data() + o.tri_offset, o.tri_count) : d.bounding_box;
+                w.triangles(box.data(), box.size());
+                --w.depth;
+                w.nl();
+                w.out += '}';
+            }
+            --w.depth;
+            w.nl();
+            w.out += "},";
+            w.key("position");
+            w.vec3(o.position);
+            w.out += ',';
+            w.key("material");
+            w.out += '{';
+            ++w.depth;
+            w.key("color");
+            w.vec3(o.color);
+            w.out += ',';
+            w.key("emmission");
+            w.vec3(o.emission);
+            w.out += ',';
+            w.key("reflect_type");
+            w.out += o.reflect_type == PT_DIFFUSE ? "\"Diffuse\"" : (o.reflect_type == PT_SPECULAR ? "\"Specular\"" : "\"Refract\"");
+            --w.depth;
+            w.nl();
+            w.out += '}';
+            --w.depth;
+            w.nl();
+            w.out += '}';
+            if (i + 1 < s->objects.size()) w.out += ',';
+        }
+        --w.depth;
+        w.nl();
+        w.out += ']';
+    }
+    w.out += ',';
+    w.key("camera");
+    w.out += '{';
+    ++w.depth;
+    w.key("position");
+    w.vec3(s->camera.position);
+    w.out += ',';
+    w.key("direction");
+    w.vec3(s->camera.direction);
+    w.out += ',';
+    w.key("focal_length");
+    w.out += fmt_f32(s->camera.focal_length);
+    w.out += ',';
+    w.key("sensor_width");
+    w.out += fmt_f32(s->camera.sensor_width);
+    w.out += ',';
+    w.key("aspect_ratio");
+    w.out += fmt_f32(s->camera.aspect_ratio);
+    --w.depth;
+    w.nl();
+    w.out += '}';
+    --w.depth;
+    w.nl();
+    w.out += '}';
+    FILE *f = fopen(path, "wb");
+    if (!f) {
+        pt::set_error(std::string("cannot create ") + path);
+        return PT_ERR_IO;
+    }
+    const size_t wr = fwrite(w.out.data(), 1, w.out.size(), f);
+    if (fclose(f) != 0 || wr != w.out.size()) {
+        pt::set_error(std::string("short write to ") + path);
+        return PT_ERR_IO;
+    }
+    return PT_OK;
+}
+
+// camera edits from a host (the GUI moves the camera, then saves: src/main.rs:245-251)
+int pt_scene_set_camera(pt_scene *s, const pt_camera *cam) {
+    if (!s || !cam) {
+        pt::set_error("NULL argument");
+        return PT_ERR_INVALID;
+    }
+    s->camera = *cam;
     return PT_OK;
 }
 

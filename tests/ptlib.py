@@ -180,6 +180,8 @@ def product():
     L.pt_scene_load.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
     L.pt_scene_free.argtypes = [C.c_void_p]
     L.pt_scene_free.restype = None
+    L.pt_scene_save.argtypes = [C.c_void_p, C.c_char_p]
+    L.pt_scene_set_camera.argtypes = [C.c_void_p, C.POINTER(PtCamera)]
     L.pt_scene_id.argtypes = [C.c_void_p]
     L.pt_scene_id.restype = C.c_char_p
     L.pt_scene_camera.argtypes = [C.c_void_p]

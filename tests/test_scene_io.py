@@ -155,3 +155,44 @@ def test_hdodec_style_pentagons_are_rejected(tmp_path):
     n = C.c_uint32()
     assert L.pt_load_off(write(tmp_path, "p.off", text).encode(), 1.0, C.byref(tris), C.byref(n)) == -7
     assert b"Invalid face" in L.pt_last_error()
+
+
+@pytest.mark.parametrize("sid", SCENES)
+def test_save_roundtrip(sid, tmp_path):
+    """pt_scene_save then pt_scene_load gives back identical flattened scenes (all six shipped scenes)."""
+    rc, h = load_c(ptlib.scene_path(sid))
+    assert rc == 0
+    out = tmp_path / "scenes"
+    out.mkdir()
+    path = str(out / (sid + ".json"))
+    assert L.pt_scene_save(h, path.encode()) == 0, L.pt_last_error()
+    rc2, h2 = load_c(path)  # MeshFile paths resolve against the repo root
+    assert rc2 == 0, L.pt_last_error()
+    for hh in (h, h2):
+        pass
+    n1, n2, m1, m2 = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+    o1, o2 = L.pt_scene_objects(h, C.byref(n1)), L.pt_scene_objects(h2, C.byref(n2))
+    t1, t2 = L.pt_scene_triangles(h, C.byref(m1)), L.pt_scene_triangles(h2, C.byref(m2))
+    assert (n1.value, m1.value) == (n2.value, m2.value)
+    assert as_bytes(o1, n1.value) == as_bytes(o2, n2.value) and as_bytes(t1, m1.value) == as_bytes(t2, m2.value)
+    assert bytes(L.pt_scene_camera(h).contents) == bytes(L.pt_scene_camera(h2).contents)
+    json.load(open(path))  # and it is valid JSON
+    L.pt_scene_free(h)
+    L.pt_scene_free(h2)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not mounted (GPU box)")
+@pytest.mark.parametrize("sid", SCENES)
+def test_saved_bytes_equal_the_files_the_reference_wrote(sid, tmp_path):
+    """The reference's scenes/*.json ARE outputs of SceneDescriptor::save (serde_json::to_string_pretty): loading
+    one and saving it again must reproduce the file byte for byte (float formatting = ryu f32, layout = 2-space
+    pretty printer).  Five of the six files predate the removal of the camera's `updating_direction` field."""
+    src = os.path.join(REF, "scenes", sid + ".json")
+    rc, h = load_c(src, base=REF)
+    assert rc == 0, L.pt_last_error()
+    path = str(tmp_path / "o.json")
+    assert L.pt_scene_save(h, path.encode()) == 0
+    ours = open(path).read()
+    theirs = open(src).read().replace('    "updating_direction": null,\n', "")
+    assert ours == theirs
+    L.pt_scene_free(h)
