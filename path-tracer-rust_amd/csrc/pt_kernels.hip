@@ -61,15 +61,17 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams F, RayQueue q, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// The BVH variant runs 1024-thread workgroups: one LDS copy of the nodes then serves 16 waves, and the walk -
+// bound by LDS / leaf-fetch latency, not by issue slots - gets twice the waves per CU to hide it.
 template <bool BVH>
-__global__ __launch_bounds__(kBlock) void k_intersect(DevScene S, RayQueue q, float2 *__restrict__ hit,
+__global__ __launch_bounds__(BVH ? kBlockBvh : kBlock, BVH ? 6 : 1) void k_intersect(DevScene S, RayQueue q, float2 *__restrict__ hit,
                                                       const uint32_t *__restrict__ cnt, uint32_t cap,
                                                       unsigned long long *__restrict__ blk_rays) {
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
     const uint32_t n = cnt[b];
     const size_t base = (size_t)b * cap;
     if (BVH && n != 0u) stage_bvh(S, dyn_lds);
-    for (uint32_t i = tid; i < n; i += kBlock) {
+    for (uint32_t i = tid; i < n; i += blockDim.x) {
         const float4 a = q.od0[base + i];
         const float2 c = q.od1[base + i];
         const HitRec h = intersect_scene_dev<BVH>(S, mk(a.x, a.y, a.z), mk(a.w, c.x, c.y), dyn_lds);
@@ -366,8 +368,8 @@ void launch_generate(hipStream_t st, uint32_t K, const FrameParams &F, const Ray
 void launch_intersect(hipStream_t st, uint32_t K, const DevScene &S, const RayQueue &q, float2 *hit,
                       const uint32_t *cnt, uint32_t cap, unsigned long long *blk_rays) {
     if (S.n_bvh_nodes != 0u)
-        hipLaunchKernelGGL(k_intersect<true>, dim3(K), dim3(kBlock), bvh_lds_bytes(S, kBlock), st, S, q, hit, cnt, cap,
-                           blk_rays);
+        hipLaunchKernelGGL(k_intersect<true>, dim3(K), dim3(kBlockBvh), bvh_lds_bytes(S, kBlockBvh), st, S, q, hit, cnt,
+                           cap, blk_rays);
     else
         hipLaunchKernelGGL(k_intersect<false>, dim3(K), dim3(kBlock), 0, st, S, q, hit, cnt, cap, blk_rays);
 }
