@@ -74,7 +74,7 @@ struct pt_ctx {
     uint32_t K = 0, cap = 0;
     DevBuf<float4> q_od0[2], q_tp[2];
     DevBuf<float2> q_od1[2], hit;
-    DevBuf<uint32_t> q_meta[2], cnt, flags;
+    DevBuf<uint32_t> cnt, flags;
     DevBuf<unsigned long long> blk_rays, acc, total_rays;
     std::vector<hipEvent_t> ev_pool;
     // state of the frame being rendered (for pt_ctx_snapshot from the progress callback)
@@ -156,7 +156,6 @@ RayQueue queue_of(pt_ctx *c, int which) {
     q.od0 = c->q_od0[which].p;
     q.od1 = c->q_od1[which].p;
     q.tp = c->q_tp[which].p;
-    q.meta = c->q_meta[which].p;
     return q;
 }
 
@@ -181,6 +180,7 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &F, hipS
     uint32_t spp_pass = (uint32_t)(want / npix);
     if (spp_pass == 0) spp_pass = 1;
     if (spp_pass > cfg->spp) spp_pass = cfg->spp;
+    if (spp_pass > kMaxPassSpp) spp_pass = kMaxPassSpp;  // sample-in-pass field of the stream bookkeeping word
     // stream b owns m consecutive pixels of the band (all samples of a pass): about 2048 streams, at most
     // kMaxStreamPixels pixels each (their radiance accumulators live in LDS inside k_shade)
     uint32_t m = (uint32_t)((npix + 2047) / 2048);
@@ -196,8 +196,7 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &F, hipS
     const size_t slots = (size_t)K * cap;
     for (int w = 0; w < 2; ++w) {
         int rc;
-        if ((rc = c->q_od0[w].ensure(slots)) || (rc = c->q_od1[w].ensure(slots)) || (rc = c->q_tp[w].ensure(slots)) ||
-            (rc = c->q_meta[w].ensure(slots)))
+        if ((rc = c->q_od0[w].ensure(slots)) || (rc = c->q_od1[w].ensure(slots)) || (rc = c->q_tp[w].ensure(slots)))
             return rc;
     }
     int rc;
@@ -252,7 +251,7 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &F, hipS
                 launch_intersect(st, K, c->scene, qin, c->hit.p, c->cnt.p + (size_t)d * K, cap, c->blk_rays.p);
             }
             launch_shade(st, K, c->scene, F, qin, qout, c->hit.p, c->cnt.p + (size_t)d * K,
-                         c->cnt.p + (size_t)(d + 1) * K, cap, c->acc.p, c->flags.p, m);
+                         c->cnt.p + (size_t)(d + 1) * K, cap, c->acc.p, c->flags.p, m, s0);
         }
         HIP_TRY(hipEventRecord(pass_done[p & 1], st));
         ++passes_done;
@@ -421,7 +420,6 @@ void pt_ctx_destroy(pt_ctx *c) {
         c->q_od0[w].release();
         c->q_od1[w].release();
         c->q_tp[w].release();
-        c->q_meta[w].release();
     }
     c->hit.release();
     c->cnt.release();

@@ -130,7 +130,20 @@ struct ShadeParams {
     uint32_t idx_begin, npix;
     uint32_t seed_lo, seed_hi;
     uint32_t debug;
+    uint32_t s0;  // first sample index of the pass
 };
+
+// Per-ray bookkeeping word as stored in a stream (4 B, the w lane of the throughput packet): a stream owns at
+// most 1024 pixels and a pass holds at most 32767 samples of a pixel, so both are stored relative to the stream /
+// pass: pixel-in-stream (10 bits) | sample-in-pass (15) | depth (4) | branch (3).
+constexpr uint32_t kMaxPassSpp = 32767u;
+PT_HD uint32_t pack_word(uint32_t pix_in_stream, uint32_t sample_in_pass, uint32_t depth, uint32_t branch) {
+    return (pix_in_stream & 1023u) | ((sample_in_pass & 32767u) << 10) | ((depth & 15u) << 25) | (branch << 29);
+}
+PT_HD uint32_t word_pix(uint32_t w) { return w & 1023u; }
+PT_HD uint32_t word_sample(uint32_t w) { return (w >> 10) & 32767u; }
+PT_HD uint32_t word_depth(uint32_t w) { return (w >> 25) & 15u; }
+PT_HD uint32_t word_branch(uint32_t w) { return w >> 29; }
 
 // ray meta word: sample index (24 bits) | depth (4 bits) | branch id (3 bits)
 PT_HD uint32_t pack_meta(uint32_t sample, uint32_t depth, uint32_t branch) {

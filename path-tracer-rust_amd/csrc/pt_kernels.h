@@ -16,8 +16,7 @@ constexpr uint32_t kLevels = 13;    // ray depths 0..11 plus the (always empty) 
 struct RayQueue {
     float4 *od0;     // origin xyz, direction x
     float2 *od1;     // direction yz
-    float4 *tp;      // throughput rgb, pixel index bits
-    uint32_t *meta;  // sample | depth | branch
+    float4 *tp;      // throughput rgb, bookkeeping word (pack_word: pixel-in-stream | sample-in-pass | depth | branch)
 };
 
 void launch_generate(hipStream_t st, uint32_t K, const FrameParams &F, const RayQueue &q, uint32_t *cnt0,
@@ -26,7 +25,7 @@ void launch_intersect(hipStream_t st, uint32_t K, const DevScene &S, const RayQu
                       const uint32_t *cnt, uint32_t cap, unsigned long long *blk_rays);
 void launch_shade(hipStream_t st, uint32_t K, const DevScene &S, const FrameParams &F, const RayQueue &qin,
                   const RayQueue &qout, const float2 *hit, const uint32_t *cnt_in, uint32_t *cnt_out, uint32_t cap,
-                  unsigned long long *acc, uint32_t *flags, uint32_t m);
+                  unsigned long long *acc, uint32_t *flags, uint32_t m, uint32_t s0);
 void launch_resolve(hipStream_t st, const unsigned long long *acc, float *out, uint32_t npix, uint32_t spp);
 void launch_mega(hipStream_t st, uint32_t grid, const DevScene &S, const FrameParams &F, unsigned long long *acc,
                  uint32_t chunk_spp, uint32_t n_chunks, unsigned long long *total_rays);

@@ -20,8 +20,8 @@
 //     flushed to the frame accumulator by plain read-modify-write stores - no global atomic in the pipeline
 //     (global 64-bit atomics cost 27 % of k_shade when they were used: profiles/README.md),
 //   * K >> 256 CUs workgroups keep every XCD busy and the hardware dispatcher balances streams of unequal decay.
-// Queue arrays (per ray): od0 = (ox,oy,oz,dx) 16 B, od1 = (dy,dz) 8 B, tp = (throughput rgb, pixel) 16 B,
-// meta 4 B; hit = (t, id) 8 B.  intersect moves 24+8 = 32 B/ray, shade 52 B in + 44 B out per survivor.
+// Queue arrays (per ray): od0 = (ox,oy,oz,dx) 16 B, od1 = (dy,dz) 8 B, tp = (throughput rgb, bookkeeping word) 16 B;
+// hit = (t, id) 8 B.  intersect moves 24+8 = 32 B/ray, shade 48 B in + 40 B out per survivor.
 #include "pt_kernels.h"
 
 namespace pt {
@@ -34,12 +34,10 @@ __device__ __forceinline__ uint32_t lane_prefix(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-__device__ __forceinline__ void store_ray(const RayQueue &q, size_t at, vec3 o, vec3 d, vec3 thr, uint32_t pix,
-                                          uint32_t meta) {
+__device__ __forceinline__ void store_ray(const RayQueue &q, size_t at, vec3 o, vec3 d, vec3 thr, uint32_t word) {
     q.od0[at] = make_float4(o.x, o.y, o.z, d.x);
     q.od1[at] = make_float2(d.y, d.z);
-    q.tp[at] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(pix));
-    q.meta[at] = meta;
+    q.tp[at] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(word));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -55,7 +53,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams F, RayQueue q, 
         const uint32_t pl = p0 + g % mb;
         const uint32_t s = s0 + g / mb;
         const PathRay r = primary_ray(F, F.idx_begin + pl, s);
-        store_ray(q, base + g, r.o, r.d, r.thr, r.pix, r.meta);
+        store_ray(q, base + g, r.o, r.d, r.thr, pack_word(g % mb, g / mb, 0u, 1u));
     }
     if (tid == 0) cnt0[b] = n;
 }
@@ -117,32 +115,28 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, ShadeParams F, Ray
     float2 n_hr = make_float2(0.0f, __int_as_float(-1));
     float4 n_a = make_float4(0, 0, 0, 0), n_tp = n_a;
     float2 n_c = make_float2(0, 0);
-    uint32_t n_meta = 0;
     if (tid < n) {
         n_hr = hit[base + tid];
         n_a = qin.od0[base + tid];
         n_c = qin.od1[base + tid];
         n_tp = qin.tp[base + tid];
-        n_meta = qin.meta[base + tid];
     }
     for (uint32_t j0 = 0; j0 < n; j0 += kBlock) {  // uniform trip count: every lane reaches the ballots
         const uint32_t i = j0 + tid;
         const float2 hr = n_hr;
         const float4 a = n_a, tp = n_tp;
         const float2 c = n_c;
-        const uint32_t meta = n_meta;
         const uint32_t i_next = i + kBlock;
         if (i_next < n) {
             n_hr = hit[base + i_next];
             n_a = qin.od0[base + i_next];
             n_c = qin.od1[base + i_next];
             n_tp = qin.tp[base + i_next];
-            n_meta = qin.meta[base + i_next];
         }
         ShadeOut so;
         so.n_rays = 0;
         so.emits = false;
-        uint32_t pix = 0;
+        uint32_t word = 0;
         if (i < n) {
             HitRec h;
             h.t = hr.x;
@@ -152,9 +146,9 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, ShadeParams F, Ray
                 in.o = mk(a.x, a.y, a.z);
                 in.d = mk(a.w, c.x, c.y);
                 in.thr = mk(tp.x, tp.y, tp.z);
-                in.pix = __float_as_uint(tp.w);
-                in.meta = meta;
-                pix = in.pix;
+                word = __float_as_uint(tp.w);
+                in.pix = F.idx_begin + p0 + word_pix(word);
+                in.meta = pack_meta(F.s0 + word_sample(word), word_depth(word), word_branch(word));
                 shade_hit(S, F, in, h, so);
                 if (so.emits && !(F.debug & 1u)) add_radiance_lds(lds_acc, m, in.pix - F.idx_begin - p0, so.contrib);
                 if (F.debug & 1u) asm volatile("" ::"v"(so.contrib.x), "v"(so.contrib.y), "v"(so.contrib.z));
@@ -170,14 +164,16 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, ShadeParams F, Ray
         if (so.n_rays >= 1) {
             const uint32_t slot = wbase + lane_prefix(m1);
             if (slot < cap)
-                store_ray(qout, base + slot, so.x, so.d0, so.thr0, pix, so.meta0);
+                store_ray(qout, base + slot, so.x, so.d0, so.thr0,
+                          pack_word(word_pix(word), word_sample(word), meta_depth(so.meta0), meta_branch(so.meta0)));
             else
                 overflow = true;
         }
         if (so.n_rays == 2) {
             const uint32_t slot = wbase + c1 + lane_prefix(m2);
             if (slot < cap)
-                store_ray(qout, base + slot, so.x, so.d1, so.thr1, pix, so.meta1);
+                store_ray(qout, base + slot, so.x, so.d1, so.thr1,
+                          pack_word(word_pix(word), word_sample(word), meta_depth(so.meta1), meta_branch(so.meta1)));
             else
                 overflow = true;
         }
@@ -375,7 +371,7 @@ void launch_intersect(hipStream_t st, uint32_t K, const DevScene &S, const RayQu
 }
 void launch_shade(hipStream_t st, uint32_t K, const DevScene &S, const FrameParams &F, const RayQueue &qin,
                   const RayQueue &qout, const float2 *hit, const uint32_t *cnt_in, uint32_t *cnt_out, uint32_t cap,
-                  unsigned long long *acc, uint32_t *flags, uint32_t m) {
+                  unsigned long long *acc, uint32_t *flags, uint32_t m, uint32_t s0) {
     const size_t lds = (size_t)3 * m * sizeof(unsigned long long) + 16;
     ShadeParams P;
     P.idx_begin = F.idx_begin;
@@ -383,6 +379,7 @@ void launch_shade(hipStream_t st, uint32_t K, const DevScene &S, const FramePara
     P.seed_lo = F.seed_lo;
     P.seed_hi = F.seed_hi;
     P.debug = F.debug;
+    P.s0 = s0;
     hipLaunchKernelGGL(k_shade, dim3(K), dim3(kBlock), lds, st, S, P, qin, qout, hit, cnt_in, cnt_out, cap, acc,
                        flags, m);
 }
