@@ -106,19 +106,28 @@ def main():
                          % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # PT_BENCH_DIST_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share devices and
+    # the band gather goes through host memory); the measured configuration is one rank per GPU over RCCL ("nccl")
+    backend = os.environ.get("PT_BENCH_DIST_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, n_dev)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     W, H, spp = args.width, args.height, args.spp
     npix = W * H
     scene = pkg.Scene(os.path.join(ROOT, "scenes", args.scene + ".json"), ROOT)
-    ctx = pkg.Context(local_rank)
+    ctx = pkg.Context(dev_index)
     ctx.set_scene(scene)  # scene tables resident in HBM before the timed region
     band = pkg.band_for_rank(npix, rank, world)
     local = torch.zeros((band[1] - band[0], 3), dtype=torch.float32, device=dev)
@@ -132,7 +141,7 @@ def main():
         ctx.set_profiling(profile)
         st = ctx.render(local.data_ptr(), W, H, spp, seed=args.seed, backend=backend, band=band,
                         rays_per_pass=args.rays_per_pass)
-        full = pkg.gather_bands(local, npix, rank, world, dist)
+        full = pkg.gather_bands(local if backend == "nccl" else local.cpu(), npix, rank, world, dist)
         return st, full
 
     def timed(backend, steps, warmup, profile):
@@ -152,10 +161,10 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-            b = torch.tensor([bounces], dtype=torch.int64, device=dev)
+            b = torch.tensor([bounces], dtype=torch.int64, device=coll_dev)
             dist.all_reduce(b, op=dist.ReduceOp.SUM)
             bounces = int(b.item())
         return dict(dt=dt, bounces=bounces, isect_rays=isect_rays, isect_ms=isect_ms, launches=launches, image=full)
@@ -176,9 +185,11 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "scenes/%s.json %dx%d @%dspp, wavefront HIP pipeline, %d band(s) + RCCL all-gather"
-                        % (args.scene, W, H, spp, world),
+            "workload": "scenes/%s.json %dx%d @%dspp, %s HIP backend, %d band(s)%s"
+                        % (args.scene, W, H, spp, args.backend, world,
+                           " + one RCCL all-gather of the framebuffer" if world > 1 else ""),
             "backend": args.backend,
+            "collective": ("RCCL all_gather_into_tensor" if backend == "nccl" else backend + " (rehearsal)") if world > 1 else None,
             "width": W, "height": H, "spp": spp, "seed": args.seed,
             "ray_bounces_per_frame": main_run["bounces"] // max(1, args.steps),
         },
