@@ -222,6 +222,11 @@ def main():
                 out["roofline"]["traffic"] = tr["hbm_bytes_per_ray"] * out["roofline"]["rays_per_launch"]
                 out["roofline"]["traffic_bytes_per_ray"] = tr["hbm_bytes_per_ray"]
                 out["roofline"]["traffic_source"] = tr.get("source")
+                if "valu" in tr:  # the resource that actually binds this kernel (from the same committed profile)
+                    out["roofline"]["binding_resource"] = {
+                        "name": "VALU instruction issue", "valu_insts_per_ray": tr["valu"]["insts_per_ray"],
+                        "valu_busy_frac": tr["valu"]["busy_frac"],
+                        "valu_wave_insts_per_s": tr["valu"]["insts_per_ray"] * out["roofline"]["intersect_rays_per_s"] / 64.0}
             except Exception:
                 pass
     if rank == 0 and world == 1 and not args.no_variants:
