@@ -199,6 +199,11 @@ typedef struct pt_scene pt_scene;
  * `path` is the JSON file; MeshFile paths are resolved against `base_dir` (the reference
  * resolves them against the process CWD; pass "." for that behaviour). */
 int pt_scene_load(const char *path, const char *base_dir, pt_scene **out);
+/* flags = PT_LOAD_TRIANGULATE additionally accepts OFF faces with more than 3 vertices (meshes/hdodec.off has
+ * pentagons) and fan-triangulates them.  An extension: the reference's load_off rejects such files
+ * (load_off.rs:73-76), so there is no reference behaviour to match beyond "a triangle stays a triangle". */
+#define PT_LOAD_TRIANGULATE 1u
+int pt_scene_load_ex(const char *path, const char *base_dir, uint32_t flags, pt_scene **out);
 /* SceneData::to_descriptor + SceneDescriptor::save (mod.rs:112-117, 127-149): the same bytes
  * serde_json::to_string_pretty writes (MeshFile objects keep their path/scale, inline meshes their
  * bounding_sphere / bounding_box). */
@@ -212,6 +217,7 @@ const pt_triangle *pt_scene_triangles(const pt_scene *s, uint32_t *n);
 
 /* load_off (load_off.rs:8-85): returns a malloc'ed triangle array (free with pt_free). */
 int pt_load_off(const char *path, float scale, pt_triangle **tris, uint32_t *n_tris);
+int pt_load_off_ex(const char *path, float scale, uint32_t flags, pt_triangle **tris, uint32_t *n_tris);
 void pt_free(void *p);
 
 /* gamma (mod.rs:57-63) and the P3 writer (mod.rs:1043-1076). */

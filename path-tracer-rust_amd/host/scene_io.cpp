@@ -282,7 +282,8 @@ bool parse_f32(const std::string &t, float *out) {
     return true;
 }
 
-int load_off_impl(const std::string &path, float scale, std::vector<pt_triangle> &out, std::string &err) {
+int load_off_impl(const std::string &path, float scale, uint32_t flags, std::vector<pt_triangle> &out,
+                  std::string &err) {
     std::ifstream f(path);
     if (!f) {
         err = "cannot open " + path;
@@ -344,20 +345,34 @@ int load_off_impl(const std::string &path, float scale, std::vector<pt_triangle>
         tk = split_ws(line);
         uint64_t idx[4];
         if (tk.size() < 4 || !parse_usize(tk[0], &idx[0]) || !parse_usize(tk[1], &idx[1]) ||
-            !parse_usize(tk[2], &idx[2]) || !parse_usize(tk[3], &idx[3]) || idx[0] != 3) {
+            !parse_usize(tk[2], &idx[2]) || !parse_usize(tk[3], &idx[3]) ||
+            (idx[0] != 3 && !(flags & PT_LOAD_TRIANGULATE)) || idx[0] < 3) {
             err = "Invalid face: " + line;  // only triangles are supported (load_off.rs:73-76)
             return PT_ERR_PARSE;
         }
-        if (idx[1] >= nv || idx[2] >= nv || idx[3] >= nv) {
-            err = "face index out of range: " + line;
+        // extension beyond the reference (no oracle there): a convex polygon v0..vk-1 becomes the fan
+        // (v0,v1,v2), (v0,v2,v3), ...; a triangle is the one-element fan, i.e. exactly the reference's case
+        std::vector<uint64_t> poly;
+        if (tk.size() < 1 + idx[0]) {
+            err = "Invalid face: " + line;
             return PT_ERR_PARSE;
         }
-        pt_triangle t;
-        const pt::vec3 a = verts[idx[1]], b = verts[idx[2]], c = verts[idx[3]];
-        t.a[0] = a.x, t.a[1] = a.y, t.a[2] = a.z;
-        t.b[0] = b.x, t.b[1] = b.y, t.b[2] = b.z;
-        t.c[0] = c.x, t.c[1] = c.y, t.c[2] = c.z;
-        out.push_back(t);
+        for (uint64_t k = 0; k < idx[0]; ++k) {
+            uint64_t vi = 0;
+            if (!parse_usize(tk[1 + (size_t)k], &vi) || vi >= nv) {
+                err = "face index out of range: " + line;
+                return PT_ERR_PARSE;
+            }
+            poly.push_back(vi);
+        }
+        for (size_t k = 1; k + 1 < poly.size(); ++k) {
+            pt_triangle t;
+            const pt::vec3 a = verts[poly[0]], b = verts[poly[k]], c = verts[poly[k + 1]];
+            t.a[0] = a.x, t.a[1] = a.y, t.a[2] = a.z;
+            t.b[0] = b.x, t.b[1] = b.y, t.b[2] = b.z;
+            t.c[0] = c.x, t.c[1] = c.y, t.c[2] = c.z;
+            out.push_back(t);
+        }
     }
     return PT_OK;
 }
@@ -527,13 +542,17 @@ std::vector<pt_triangle> box_triangles(const pt_triangle *t, size_t n) {
 extern "C" {
 
 int pt_load_off(const char *path, float scale, pt_triangle **tris, uint32_t *n_tris) {
+    return pt_load_off_ex(path, scale, 0u, tris, n_tris);
+}
+
+int pt_load_off_ex(const char *path, float scale, uint32_t flags, pt_triangle **tris, uint32_t *n_tris) {
     if (!path || !tris || !n_tris) {
         pt::set_error("NULL argument");
         return PT_ERR_INVALID;
     }
     std::vector<pt_triangle> v;
     std::string err;
-    int rc = load_off_impl(path, scale, v, err);
+    int rc = load_off_impl(path, scale, flags, v, err);
     if (rc) {
         pt::set_error(err);
         return rc;
@@ -551,6 +570,10 @@ int pt_load_off(const char *path, float scale, pt_triangle **tris, uint32_t *n_t
 void pt_free(void *p) { free(p); }
 
 int pt_scene_load(const char *path, const char *base_dir, pt_scene **out) {
+    return pt_scene_load_ex(path, base_dir, 0u, out);
+}
+
+int pt_scene_load_ex(const char *path, const char *base_dir, uint32_t flags, pt_scene **out) {
     if (!path || !out) {
         pt::set_error("NULL argument");
         return PT_ERR_INVALID;
@@ -647,7 +670,7 @@ int pt_scene_load(const char *path, const char *base_dir, pt_scene **out) {
             std::vector<pt_triangle> tl;
             std::string err;
             const std::string full = (jp_->str.size() && jp_->str[0] == '/') ? jp_->str : base + "/" + jp_->str;
-            int rc = load_off_impl(full, scale, tl, err);
+            int rc = load_off_impl(full, scale, flags, tl, err);
             if (rc) {
                 pt::set_error("scene: " + where + ": " + err);
                 return rc;

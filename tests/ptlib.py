@@ -15,7 +15,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "path-tracer-rust_amd")
 ORACLE_SO = os.path.join(ROOT, "oracle", "libpt_oracle.so")
 PRODUCT_SO = os.path.join(PKG, "libptrace_hip.so")
-HOST_SO = os.path.join(PKG, "libptrace_host.so")
 
 f3 = C.c_float * 3
 
@@ -178,6 +177,8 @@ def product():
                             C.POINTER(PtTriangle), C.c_uint32, fp, C.c_void_p, C.c_void_p, C.c_void_p,
                             C.POINTER(PtStats)]
     L.pt_scene_load.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
+    L.pt_scene_load_ex.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.pt_load_off_ex.argtypes = [C.c_char_p, C.c_float, C.c_uint32, C.POINTER(C.POINTER(PtTriangle)), u32p]
     L.pt_scene_free.argtypes = [C.c_void_p]
     L.pt_scene_free.restype = None
     L.pt_scene_save.argtypes = [C.c_void_p, C.c_char_p]
@@ -207,8 +208,8 @@ def _v3(v):
     return f3(*[float(np.float32(x)) for x in v])
 
 
-def load_off_py(path, scale):
-    """load_off.rs:8-85 in Python (f32 arithmetic through numpy)."""
+def load_off_py(path, scale, triangulate=False):
+    """load_off.rs:8-85 in Python (f32 arithmetic through numpy); triangulate=True: fan over polygon faces."""
     lines = []
     for l in open(path):
         l = l.strip()
@@ -221,8 +222,10 @@ def load_off_py(path, scale):
     tris = []
     for l in lines[2 + nv:2 + nv + nf]:
         t = l.split()
-        assert int(t[0]) == 3
-        tris.append((verts[int(t[1])], verts[int(t[2])], verts[int(t[3])]))
+        k = int(t[0])
+        assert k == 3 or (triangulate and k > 3)
+        for j in range(2, k):
+            tris.append((verts[int(t[1])], verts[int(t[j])], verts[int(t[j + 1])]))
     return tris
 
 
@@ -290,7 +293,7 @@ def make_tri(a, b, c):
     return t
 
 
-def load_scene_py(path, base_dir=None):
+def load_scene_py(path, base_dir=None, triangulate=False):
     """SceneDescriptor::load + to_data (mod.rs:92-110,304-318) in Python."""
     base_dir = base_dir or os.path.dirname(os.path.dirname(os.path.abspath(path)))
     d = json.load(open(path))
@@ -305,7 +308,7 @@ def load_scene_py(path, base_dir=None):
             objs.append(make_sphere(od["position"], val["radius"], m["color"], m["emmission"], m["reflect_type"]))
             continue
         if kind == "MeshFile":
-            tl = load_off_py(os.path.join(base_dir, val["path"]), val["scale"])
+            tl = load_off_py(os.path.join(base_dir, val["path"]), val["scale"], triangulate)
             tlist = [make_tri(a, b, c_) for a, b, c_ in tl]
             arr = (PtTriangle * len(tlist))(*tlist)
             ctr = (C.c_float * 3)()

@@ -440,3 +440,16 @@ def test_largest_frame_geometry(gpu):
     for idx in idxs:
         O.pto_render_pixel(C.byref(ps), C.byref(cfg), int(idx), _np_f(px), None)
         assert float(np.abs(px - a[idx]).max()) <= TOL, idx
+
+
+def test_hdodec_extension_parity(gpu):
+    """Fan-triangulated hdodec.off (36 triangles -> BVH path) inside the cornell walls: GPU == oracle on the same
+    triangles (the triangulation itself has no reference behaviour to match)."""
+    sc = ptlib.load_scene_py(ptlib.scene_path("mesh-hdodec"), triangulate=True)
+    w, h, spp = 96, 64, 8
+    want, cnt, _ = ptlib.oracle_render(sc, w, h, spp, 4)
+    for backend in (0, 1):
+        got, st = gpu_render(gpu, sc, w, h, spp, 4, backend)
+        assert st.ray_bounces == cnt.ray_bounces
+        assert float(np.abs(got - want).max()) <= TOL
+    assert (want[:, 0] != want[:, 2]).any()

@@ -148,6 +148,23 @@ def test_off_loader_semantics(tmp_path):
     assert L.pt_load_off(b"/nonexistent.off", 1.0, C.byref(tris), C.byref(n)) == -6
 
 
+def test_hdodec_fan_triangulation_extension():
+    """meshes/hdodec.off (12 pentagons) is rejected as the reference rejects it, and loads as 36 fan triangles
+    with PT_LOAD_TRIANGULATE; the flattened scene equals the Python reading of the same rule."""
+    path = ptlib.scene_path("mesh-hdodec")
+    h = C.c_void_p()
+    assert L.pt_scene_load(path.encode(), ptlib.ROOT.encode(), C.byref(h)) == -7
+    assert L.pt_scene_load_ex(path.encode(), ptlib.ROOT.encode(), 1, C.byref(h)) == 0, L.pt_last_error()
+    py = ptlib.load_scene_py(path, triangulate=True)
+    n, m = C.c_uint32(), C.c_uint32()
+    objs = L.pt_scene_objects(h, C.byref(n))
+    tris = L.pt_scene_triangles(h, C.byref(m))
+    assert objs[0].tri_count == 36 and m.value == 36 + 14
+    assert as_bytes(objs, n.value) == bytes(py.objs)[: C.sizeof(ptlib.PtObject) * n.value]
+    assert as_bytes(tris, m.value) == bytes(py.tris)[: C.sizeof(ptlib.PtTriangle) * m.value]
+    L.pt_scene_free(h)
+
+
 def test_hdodec_style_pentagons_are_rejected(tmp_path):
     """The reference cannot load meshes/hdodec.off (pentagon faces, load_off.rs:73-76); neither can we."""
     text = "OFF\n5 1 0\n0 0 0\n1 0 0\n1 1 0\n0.5 1.5 0\n0 1 0\n5 0 1 2 3 4\n"

@@ -73,6 +73,30 @@ def main():
     with open(os.path.join(root, "meshes", "mctri.off"), "w") as f:
         f.write("\n".join(out) + "\n")
     print("wrote meshes/mctri.off", nv, nf)
+    # hdodec.off: polygon faces (the reference cannot load it; used by the PT_LOAD_TRIANGULATE extension)
+    src = [l.strip() for l in open(os.path.join(ref, "meshes", "hdodec.off"))]
+    lines = [l for l in src if l and not l.startswith("#")]
+    nv, nf, ne = map(int, lines[1].split())
+    out = ["OFF",
+           "# hdodec: %d vertices, %d pentagon faces (imported from the reference's meshes/hdodec.off; the reference's" % (nv, nf),
+           "# load_off rejects non-triangle faces, this repo can fan-triangulate them on request: PT_LOAD_TRIANGULATE)",
+           "%d %d %d" % (nv, nf, ne)]
+    for l in lines[2:2 + nv]:
+        out.append(" ".join(f32s(np.float32(t)) for t in l.split()))
+    for l in lines[2 + nv:2 + nv + nf]:
+        t = l.split()
+        out.append(" ".join(t[:1 + int(t[0])]))
+    with open(os.path.join(root, "meshes", "hdodec.off"), "w") as f:
+        f.write("\n".join(out) + "\n")
+    # a scene that uses it: mesh.json with the mesh file swapped (not a reference scene)
+    d = json.load(open(os.path.join(ref, "scenes", "mesh.json")))
+    d["id"] = "mesh-hdodec"
+    d["objects"][0]["type_"] = {"MeshFile": {"path": "meshes/hdodec.off", "scale": 0.9}}
+    d["objects"][0]["position"] = [0.0, -1.0, 0.0]
+    out = enc.encode(conv(d)).replace('{"type_"', '\n{"type_"').replace('],"camera"', '\n],"camera"')
+    with open(os.path.join(root, "scenes", "mesh-hdodec.json"), "w") as f:
+        f.write(out + "\n")
+    print("wrote meshes/hdodec.off and scenes/mesh-hdodec.json")
 
 
 if __name__ == "__main__":
