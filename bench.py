@@ -108,9 +108,9 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     # PT_BENCH_DIST_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share devices and
     # the band gather goes through host memory); the measured configuration is one rank per GPU over RCCL ("nccl")
-    backend = os.environ.get("PT_BENCH_DIST_BACKEND", "nccl")
+    dist_backend = os.environ.get("PT_BENCH_DIST_BACKEND", "nccl")
     n_dev = torch.cuda.device_count()
-    dev_index = local_rank if backend == "nccl" else local_rank % max(1, n_dev)
+    dev_index = local_rank if dist_backend == "nccl" else local_rank % max(1, n_dev)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
@@ -118,19 +118,23 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
+        if dist_backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
-            dist.init_process_group(backend=backend)
-    coll_dev = dev if backend == "nccl" else torch.device("cpu")
+            dist.init_process_group(backend=dist_backend)
+    coll_dev = dev if dist_backend == "nccl" else torch.device("cpu")
 
     W, H, spp = args.width, args.height, args.spp
     npix = W * H
     scene = pkg.Scene(os.path.join(ROOT, "scenes", args.scene + ".json"), ROOT)
     ctx = pkg.Context(dev_index)
     ctx.set_scene(scene)  # scene tables resident in HBM before the timed region
-    band = pkg.band_for_rank(npix, rank, world)
-    local = torch.zeros((band[1] - band[0], 3), dtype=torch.float32, device=dev)
+    # rank r renders image rows r, r+N, r+2N, ... (chunk = one row of framebuffer indices): contiguous eighths of
+    # this image differ by up to 1.31x in ray bounces, interleaved rows by < 1 %
+    chunk = W
+    counts, _ = pkg.chunk_owner_map(npix, world, chunk)
+    chunks = (chunk, rank, world) if world > 1 else None
+    local = torch.zeros((counts[rank], 3), dtype=torch.float32, device=dev)
 
     def barrier():
         if dist is not None:
@@ -139,9 +143,9 @@ def main():
 
     def step(backend, profile):
         ctx.set_profiling(profile)
-        st = ctx.render(local.data_ptr(), W, H, spp, seed=args.seed, backend=backend, band=band,
+        st = ctx.render(local.data_ptr(), W, H, spp, seed=args.seed, backend=backend, chunks=chunks,
                         rays_per_pass=args.rays_per_pass)
-        full = pkg.gather_bands(local if backend == "nccl" else local.cpu(), npix, rank, world, dist)
+        full = pkg.gather_chunks(local if dist_backend == "nccl" else local.cpu(), npix, rank, world, chunk, dist)
         return st, full
 
     def timed(backend, steps, warmup, profile):
@@ -187,9 +191,11 @@ def main():
         "config": {
             "workload": "scenes/%s.json %dx%d @%dspp, %s HIP backend, %d band(s)%s"
                         % (args.scene, W, H, spp, args.backend, world,
-                           " + one RCCL all-gather of the framebuffer" if world > 1 else ""),
+                           " (interleaved rows) + one RCCL all-gather of the framebuffer" if world > 1 else ""),
             "backend": args.backend,
-            "collective": ("RCCL all_gather_into_tensor" if backend == "nccl" else backend + " (rehearsal)") if world > 1 else None,
+            "collective": ("RCCL all_gather_into_tensor" if dist_backend == "nccl" else dist_backend + " (rehearsal)")
+                          if world > 1 else None,
+            "partition": "rows interleaved over ranks (chunk = %d pixels)" % chunk if world > 1 else "whole frame",
             "width": W, "height": H, "spp": spp, "seed": args.seed,
             "ray_bounces_per_frame": main_run["bounces"] // max(1, args.steps),
         },

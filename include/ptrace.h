@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 1
+#define PT_ABI_VERSION 2
 
 /* status codes (reference behaviour: unwrap() panics, mod.rs:96,309,1032,1042,1093) */
 #define PT_OK 0
@@ -96,6 +96,14 @@ typedef struct pt_config {
     uint32_t idx_end;
     uint32_t rays_per_pass; /* wavefront: primary rays generated per pass; 0 = library default */
     uint32_t flags;
+    /* Interleaved partition of the band for load balance across ranks (the cost of a pixel varies over the
+     * image: contiguous eighths of cornell.json differ by up to 1.31x).  The band is cut into chunks of
+     * chunk_pixels framebuffer indices; this call renders chunks chunk_first, chunk_first+chunk_step, ... and
+     * writes them back to back into the output.  chunk_step = 0 or 1: the whole band (the other two ignored). */
+    uint32_t chunk_pixels;
+    uint32_t chunk_first;
+    uint32_t chunk_step;
+    uint32_t reserved;
 } pt_config;
 
 typedef struct pt_stats {
@@ -131,9 +139,12 @@ void pt_ctx_destroy(pt_ctx *ctx);
 int pt_ctx_set_scene(pt_ctx *ctx, const pt_camera *cam, const pt_object *objs, uint32_t n_objs,
                      const pt_triangle *tris, uint32_t n_tris);
 
-/* Render the band [idx_begin, idx_end) into DEVICE memory: d_out_rgb holds
- * (idx_end-idx_begin)*3 floats, element (idx-idx_begin)*3+c, linear, clamped to [0,1] — the
- * memory image of the reference's Vec<Vec3> slice (mod.rs:1013-1014, 852-856).
+/* Number of pixels a call with this config renders (the band, or this rank's chunks of it); 0 on a bad config. */
+uint32_t pt_config_pixels(const pt_config *cfg);
+
+/* Render the band [idx_begin, idx_end) (or this rank's chunks of it) into DEVICE memory: d_out_rgb holds
+ * pt_config_pixels(cfg)*3 floats, pixel k of the call at element k*3+c, linear, clamped to [0,1] — for an
+ * un-chunked band the memory image of the reference's Vec<Vec3> slice (mod.rs:1013-1014, 852-856).
  * `hip_stream` is a hipStream_t (NULL = the context's own stream).  Blocking. */
 int pt_ctx_render(pt_ctx *ctx, const pt_config *cfg, void *d_out_rgb, void *hip_stream,
                   const volatile uint8_t *cancel, pt_progress_fn cb, void *user, pt_stats *stats);

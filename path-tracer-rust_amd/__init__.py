@@ -38,7 +38,8 @@ class pt_object(C.Structure):
 class pt_config(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("spp", C.c_uint32), ("backend", C.c_uint32),
                 ("seed", C.c_uint64), ("idx_begin", C.c_uint32), ("idx_end", C.c_uint32),
-                ("rays_per_pass", C.c_uint32), ("flags", C.c_uint32)]
+                ("rays_per_pass", C.c_uint32), ("flags", C.c_uint32), ("chunk_pixels", C.c_uint32),
+                ("chunk_first", C.c_uint32), ("chunk_step", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class pt_stats(C.Structure):
@@ -138,11 +139,14 @@ class Context:
         _check(lib().pt_ctx_set_profiling(self._h, 1 if on else 0))
 
     def render(self, out_ptr, width, height, spp, seed=1, backend="wavefront", band=None, rays_per_pass=0,
-               stream=None):
-        """Render band [begin,end) (default whole frame) into device memory at out_ptr ((end-begin)*3 floats)."""
+               stream=None, chunks=None):
+        """Render band [begin,end) (default whole frame) — or, with chunks=(chunk_pixels, first, step), this rank's
+        interleaved chunks of it — into device memory at out_ptr (owned pixels * 3 floats)."""
         cfg = pt_config(width, height, spp, BACKENDS[backend], seed, 0, 0, rays_per_pass, 0)
         if band is not None:
             cfg.idx_begin, cfg.idx_end = band
+        if chunks is not None:
+            cfg.chunk_pixels, cfg.chunk_first, cfg.chunk_step = chunks
         st = pt_stats()
         _check(lib().pt_ctx_render(self._h, C.byref(cfg), C.c_void_p(out_ptr), C.c_void_p(stream or 0), None, None,
                                    None, C.byref(st)))
@@ -166,6 +170,44 @@ def band_for_rank(npix, rank, world):
     if not (0 <= rank < world):
         raise ValueError("rank outside world")
     return (npix * rank) // world, (npix * (rank + 1)) // world
+
+
+def chunk_owner_map(npix, world, chunk_pixels):
+    """Interleaved partition: chunk c (chunk_pixels consecutive framebuffer indices) belongs to rank c % world.
+    Returns (counts, index) where counts[r] = pixels of rank r and index[r] = the framebuffer indices of rank r's
+    pixels in the order pt_ctx_render writes them (its chunks back to back)."""
+    import torch
+    idx = torch.arange(npix, dtype=torch.int64)
+    owner = (idx // chunk_pixels) % world
+    index = [idx[owner == r] for r in range(world)]
+    return [int(i.numel()) for i in index], index
+
+
+def gather_chunks(local, npix, rank, world, chunk_pixels, dist=None):
+    """One all-gather of the per-rank chunk buffers ([owned pixels, 3]) and the permutation back to framebuffer
+    order.  Equal shares (npix a multiple of world*chunk_pixels) use all_gather_into_tensor + a strided view copy."""
+    import torch
+    if world == 1:
+        return local
+    if dist is None:
+        import torch.distributed as dist
+    counts, index = chunk_owner_map(npix, world, chunk_pixels)
+    assert local.shape[0] == counts[rank]
+    if len(set(counts)) == 1 and npix % (world * chunk_pixels) == 0:
+        flat = torch.empty((npix, 3), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(flat, local.contiguous())
+        rounds = npix // (world * chunk_pixels)
+        # flat is [rank][round][chunk_pixels]; the frame is [round][rank][chunk_pixels]
+        return flat.view(world, rounds, chunk_pixels, 3).permute(1, 0, 2, 3).reshape(npix, 3)
+    m = max(counts)
+    padded = torch.zeros((m, 3), dtype=local.dtype, device=local.device)
+    padded[: local.shape[0]] = local
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded)
+    full = torch.empty((npix, 3), dtype=local.dtype, device=local.device)
+    for r in range(world):
+        full[index[r].to(local.device)] = parts[r][: counts[r]]
+    return full
 
 
 def gather_bands(local, npix, rank, world, dist=None):

@@ -118,9 +118,26 @@ int check_cfg(const pt_config *cfg, uint32_t *idx_begin, uint32_t *idx_end) {
         set_error("unknown backend");
         return PT_ERR_INVALID;
     }
+    if (cfg->chunk_step > 1u && (cfg->chunk_pixels == 0u || cfg->chunk_first >= cfg->chunk_step)) {
+        set_error("chunk_pixels must be positive and chunk_first < chunk_step");
+        return PT_ERR_INVALID;
+    }
     *idx_begin = b;
     *idx_end = e;
     return PT_OK;
+}
+
+// pixels of the band [b, e) that fall into chunks first, first+step, ... (all of them when step <= 1)
+uint32_t owned_pixels(const pt_config *cfg, uint32_t b, uint32_t e) {
+    const uint64_t span = e - b;
+    if (cfg->chunk_step <= 1u) return (uint32_t)span;
+    const uint64_t C = cfg->chunk_pixels, n_chunks = (span + C - 1) / C;
+    uint64_t total = 0;
+    for (uint64_t c = cfg->chunk_first; c < n_chunks; c += cfg->chunk_step) {
+        const uint64_t lo = c * C, hi = (lo + C < span) ? lo + C : span;
+        total += hi - lo;
+    }
+    return (uint32_t)total;
 }
 
 FrameParams make_frame(const pt_ctx *ctx, const pt_config *cfg, uint32_t idx_begin, uint32_t idx_end) {
@@ -131,7 +148,10 @@ FrameParams make_frame(const pt_ctx *ctx, const pt_config *cfg, uint32_t idx_beg
     F.height = cfg->height;
     F.spp = cfg->spp;
     F.idx_begin = idx_begin;
-    F.npix = idx_end - idx_begin;
+    F.npix = owned_pixels(cfg, idx_begin, idx_end);
+    F.chunk_pixels = cfg->chunk_pixels;
+    F.chunk_first = cfg->chunk_first;
+    F.chunk_step = cfg->chunk_step;
     F.seed_lo = (uint32_t)cfg->seed;
     F.seed_hi = (uint32_t)(cfg->seed >> 32);
     F.cam_px = ctx->cam.position[0];
@@ -359,6 +379,12 @@ const char *pt_last_error(void) { return g_last_error.c_str(); }
 int pt_abi_version(void) { return PT_ABI_VERSION; }
 int pt_device_count(void) { return device_count_quiet(); }
 
+uint32_t pt_config_pixels(const pt_config *cfg) {
+    uint32_t b = 0, e = 0;
+    if (check_cfg(cfg, &b, &e) != PT_OK) return 0;
+    return owned_pixels(cfg, b, e);
+}
+
 int pt_camera_basis(const pt_camera *cam, float lens_center[3], float su[3], float sv[3]) {
     if (!cam || !lens_center || !su || !sv) {
         set_error("NULL argument");
@@ -541,6 +567,7 @@ int pt_ctx_render(pt_ctx *c, const pt_config *cfg, void *d_out_rgb, void *hip_st
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     const FrameParams F = make_frame(c, cfg, ib, ie);
     if (stats) memset(stats, 0, sizeof *stats);
+    if (F.npix == 0u) return PT_OK;  // this rank owns no chunk of the band
     c->live_npix = F.npix;
     c->live_spp_issued = 0;
     c->live_stream = st;
@@ -684,7 +711,9 @@ static int render_band_to_host(int dev, const pt_config *cfg, const pt_camera *c
     if (!rc) rc = pt_ctx_create(dev, &c);
     if (!rc) rc = pt_ctx_set_scene(c, cam, objs, n_objs, tris, n_tris);
     float *d_out = nullptr;
-    const size_t nfl = (size_t)(ie - ib) * 3;
+    const uint32_t own = rc ? 0u : owned_pixels(cfg, ib, ie);
+    const size_t nfl = (size_t)own * 3;
+    if (!rc && own == 0u) return PT_OK;
     if (!rc) {
         hipError_t e = hipMalloc((void **)&d_out, nfl * sizeof(float));
         if (e != hipSuccess) {
@@ -695,7 +724,20 @@ static int render_band_to_host(int dev, const pt_config *cfg, const pt_camera *c
     if (!rc) {
         rc = pt_ctx_render(c, cfg, d_out, nullptr, cancel, cb, user, stats);
         if (rc == PT_OK || rc == PT_CANCELLED) {
-            hipError_t e = hipMemcpy(out_rgb + (size_t)ib * 3, d_out, nfl * sizeof(float), hipMemcpyDeviceToHost);
+            hipError_t e = hipSuccess;
+            if (cfg->chunk_step <= 1u) {
+                e = hipMemcpy(out_rgb + (size_t)ib * 3, d_out, nfl * sizeof(float), hipMemcpyDeviceToHost);
+            } else {  // chunks go back to their places in the frame
+                std::vector<float> tmp(nfl);
+                e = hipMemcpy(tmp.data(), d_out, nfl * sizeof(float), hipMemcpyDeviceToHost);
+                const uint64_t span = ie - ib, C = cfg->chunk_pixels;
+                size_t at = 0;
+                for (uint64_t ck = cfg->chunk_first; e == hipSuccess && ck * C < span; ck += cfg->chunk_step) {
+                    const uint64_t lo = ck * C, hi = (lo + C < span) ? lo + C : span;
+                    memcpy(out_rgb + ((size_t)ib + lo) * 3, tmp.data() + at, (size_t)(hi - lo) * 3 * sizeof(float));
+                    at += (size_t)(hi - lo) * 3;
+                }
+            }
             if (e != hipSuccess) {
                 set_error(std::string("hipMemcpy(out): ") + hipGetErrorString(e));
                 rc = PT_ERR_HIP;
@@ -735,9 +777,9 @@ int pt_render_multi(const pt_config *cfg, uint32_t n_ranks, const pt_camera *cam
         set_error("no HIP device: libptrace_hip has no CPU fallback");
         return PT_ERR_NO_DEVICE;
     }
-    // rank r renders the r-th contiguous slice of [ib, ie) on device r mod n_dev; pixels are independent and the
-    // RNG is keyed on the global pixel index, so the image does not depend on n_ranks (mod.rs:1021-1023)
-    const uint64_t span = ie - ib;
+    // rank r renders the chunks r, r+n_ranks, ... of [ib, ie) (one chunk = one image row) on device r mod n_dev:
+    // interleaving evens out the cost per rank; pixels are independent and the RNG is keyed on the global pixel
+    // index, so the image does not depend on n_ranks (mod.rs:1021-1023)
     std::vector<pt_config> cfgs(n_ranks, *cfg);
     std::vector<pt_stats> sts(n_ranks);
     std::vector<int> rcs(n_ranks, PT_OK);
@@ -745,9 +787,14 @@ int pt_render_multi(const pt_config *cfg, uint32_t n_ranks, const pt_camera *cam
     std::vector<std::thread> th;
     const double t0 = now_ms();
     for (uint32_t r = 0; r < n_ranks; ++r) {
-        cfgs[r].idx_begin = ib + (uint32_t)(span * r / n_ranks);
-        cfgs[r].idx_end = ib + (uint32_t)(span * (r + 1) / n_ranks);
-        if (cfgs[r].idx_begin == cfgs[r].idx_end) continue;  // more ranks than pixels
+        cfgs[r].idx_begin = ib;
+        cfgs[r].idx_end = ie;
+        if (n_ranks > 1) {
+            cfgs[r].chunk_pixels = cfg->width;
+            cfgs[r].chunk_first = r;
+            cfgs[r].chunk_step = n_ranks;
+        }
+        if (owned_pixels(&cfgs[r], ib, ie) == 0u) continue;  // more ranks than chunks
         th.emplace_back([&, r]() {
             rcs[r] = render_band_to_host((int)(r % (uint32_t)n_dev), &cfgs[r], cam, objs, n_objs, tris, n_tris, out_rgb,
                                          cancel, r == 0 ? cb : nullptr, user, &sts[r], &errs[r]);

@@ -123,7 +123,16 @@ struct FrameParams {
     float su_x, su_y, su_z;        // orthogonals().0
     float sv_x, sv_y, sv_z;        // orthogonals().1
     uint32_t debug;                // ablation switches for profiling builds (PT_DEBUG env): 0 in production
+    uint32_t chunk_pixels, chunk_first, chunk_step;  // interleaved partition (chunk_step <= 1: contiguous band)
 };
+
+// framebuffer index of the k-th pixel of this call (identity + idx_begin for a contiguous band)
+template <class Params>
+PT_HD uint32_t global_pixel(const Params &F, uint32_t k) {
+    if (F.chunk_step <= 1u) return F.idx_begin + k;
+    const uint32_t c = k / F.chunk_pixels, w = k - c * F.chunk_pixels;
+    return F.idx_begin + (F.chunk_first + c * F.chunk_step) * F.chunk_pixels + w;
+}
 
 // the part of FrameParams the shading step needs (keeps k_shade's kernel arguments - SGPRs - small)
 struct ShadeParams {
@@ -131,6 +140,7 @@ struct ShadeParams {
     uint32_t seed_lo, seed_hi;
     uint32_t debug;
     uint32_t s0;  // first sample index of the pass
+    uint32_t chunk_pixels, chunk_first, chunk_step;
 };
 
 // Per-ray bookkeeping word as stored in a stream (4 B, the w lane of the throughput packet): a stream owns at

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams F, RayQueue q, 
     for (uint32_t g = tid; g < n; g += kBlock) {
         const uint32_t pl = p0 + g % mb;
         const uint32_t s = s0 + g / mb;
-        const PathRay r = primary_ray(F, F.idx_begin + pl, s);
+        const PathRay r = primary_ray(F, global_pixel(F, pl), s);
         store_ray(q, base + g, r.o, r.d, r.thr, pack_word(g % mb, g / mb, 0u, 1u));
     }
     if (tid == 0) cnt0[b] = n;
@@ -147,10 +147,10 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, ShadeParams F, Ray
                 in.d = mk(a.w, c.x, c.y);
                 in.thr = mk(tp.x, tp.y, tp.z);
                 word = __float_as_uint(tp.w);
-                in.pix = F.idx_begin + p0 + word_pix(word);
+                in.pix = global_pixel(F, p0 + word_pix(word));
                 in.meta = pack_meta(F.s0 + word_sample(word), word_depth(word), word_branch(word));
                 shade_hit(S, F, in, h, so);
-                if (so.emits && !(F.debug & 1u)) add_radiance_lds(lds_acc, m, in.pix - F.idx_begin - p0, so.contrib);
+                if (so.emits && !(F.debug & 1u)) add_radiance_lds(lds_acc, m, word_pix(word), so.contrib);
                 if (F.debug & 1u) asm volatile("" ::"v"(so.contrib.x), "v"(so.contrib.y), "v"(so.contrib.z));
             }
         }
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(kBlock) void k_mega(DevScene S, FrameParams F, unsi
                     sp = 0;
                     active = true;
                 } else if (s < s_end) {
-                    cur = primary_ray(F, F.idx_begin + pl, s);
+                    cur = primary_ray(F, global_pixel(F, pl), s);
                     ++s;
                     active = true;
                 }
@@ -380,6 +380,9 @@ void launch_shade(hipStream_t st, uint32_t K, const DevScene &S, const FramePara
     P.seed_hi = F.seed_hi;
     P.debug = F.debug;
     P.s0 = s0;
+    P.chunk_pixels = F.chunk_pixels;
+    P.chunk_first = F.chunk_first;
+    P.chunk_step = F.chunk_step;
     hipLaunchKernelGGL(k_shade, dim3(K), dim3(kBlock), lds, st, S, P, qin, qout, hit, cnt_in, cnt_out, cap, acc,
                        flags, m);
 }

@@ -37,7 +37,8 @@ class PtObject(C.Structure):
 class PtConfig(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("spp", C.c_uint32), ("backend", C.c_uint32),
                 ("seed", C.c_uint64), ("idx_begin", C.c_uint32), ("idx_end", C.c_uint32),
-                ("rays_per_pass", C.c_uint32), ("flags", C.c_uint32)]
+                ("rays_per_pass", C.c_uint32), ("flags", C.c_uint32), ("chunk_pixels", C.c_uint32),
+                ("chunk_first", C.c_uint32), ("chunk_step", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class PtStats(C.Structure):
@@ -150,6 +151,8 @@ def product():
     L.pt_device_count.restype = C.c_int
     L.pt_camera_basis.argtypes = [C.POINTER(PtCamera), fp, fp, fp]
     L.pt_mesh_bounding_sphere.argtypes = [C.POINTER(PtTriangle), C.c_uint32, fp, fp]
+    L.pt_config_pixels.argtypes = [C.POINTER(PtConfig)]
+    L.pt_config_pixels.restype = C.c_uint32
     L.pt_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
     L.pt_ctx_destroy.argtypes = [C.c_void_p]
     L.pt_ctx_destroy.restype = None

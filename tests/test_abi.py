@@ -31,13 +31,13 @@ def test_every_declared_symbol_is_exported():
 
 
 def test_version_and_struct_sizes():
-    assert L.pt_abi_version() == 1
+    assert L.pt_abi_version() == 2
     assert b"gfx950" in L.pt_version()
     # POD layout the Rust/cgo/ctypes side must match (include/ptrace.h)
     assert C.sizeof(ptlib.PtCamera) == 36
     assert C.sizeof(ptlib.PtTriangle) == 36
     assert C.sizeof(ptlib.PtObject) == 72
-    assert C.sizeof(ptlib.PtConfig) == 40
+    assert C.sizeof(ptlib.PtConfig) == 56
     assert C.sizeof(ptlib.PtStats) == 56
 
 

@@ -453,3 +453,52 @@ def test_hdodec_extension_parity(gpu):
         assert st.ray_bounces == cnt.ray_bounces
         assert float(np.abs(got - want).max()) <= TOL
     assert (want[:, 0] != want[:, 2]).any()
+
+
+def test_interleaved_chunks_equal_whole_frame(gpu):
+    """The multi-GPU partition of bench.py: rank r renders chunks r, r+N, ... of the frame into a dense buffer.
+    Reassembled by chunk index the N buffers are the one-call frame, bit for bit (incl. a partial last chunk, more
+    ranks than chunks, and chunking inside a band)."""
+    L, ctx = gpu
+    sc = ptlib.load_scene_py(ptlib.scene_path("cornell"))
+    set_scene(gpu, sc)
+    w, h, spp = 50, 33, 6
+    npix = w * h
+    whole, st = gpu_render(gpu, sc, w, h, spp, 12)
+
+    def chunked(backend, C_, n, band=(0, 0)):
+        b0, e0 = band if band != (0, 0) else (0, npix)
+        img = np.zeros_like(whole)
+        total = 0
+        for r in range(n):
+            cfg = PtConfig(w, h, spp, backend, 12, band[0], band[1], 0, 0, C_, r, n, 0)
+            own = L.pt_config_pixels(C.byref(cfg))
+            span = e0 - b0
+            idx = np.arange(span)
+            mine = idx[(idx // C_) % n == r] + b0
+            assert own == len(mine)
+            if own == 0:
+                continue
+            d_out = C.c_void_p()
+            assert L.pt_device_malloc(0, own * 12, C.byref(d_out)) == 0
+            s2 = PtStats()
+            rc = L.pt_ctx_render(ctx, C.byref(cfg), d_out, None, None, None, None, C.byref(s2))
+            assert rc == 0, L.pt_last_error()
+            part = np.zeros((own, 3), dtype=np.float32)
+            assert L.pt_device_download(0, part.ctypes.data_as(C.c_void_p), d_out, own * 12) == 0
+            L.pt_device_free(0, d_out)
+            img[mine] = part
+            total += s2.ray_bounces
+        return img, total
+
+    for backend in (0, 1):
+        for C_, n in ((w, 2), (w, 8), (64, 3), (7, 5), (npix, 4), (1000, 40)):
+            img, total = chunked(backend, C_, n)
+            assert np.array_equal(img, whole), (backend, C_, n)
+            assert total == st.ray_bounces
+    img, _ = chunked(0, 32, 3, band=(100, 1300))
+    assert np.array_equal(img[100:1300], whole[100:1300]) and not img[:100].any() and not img[1300:].any()
+    bad = PtConfig(w, h, spp, 0, 12, 0, 0, 0, 0, 0, 1, 2, 0)   # chunk_pixels == 0
+    assert L.pt_config_pixels(C.byref(bad)) == 0
+    bad = PtConfig(w, h, spp, 0, 12, 0, 0, 0, 0, 8, 2, 2, 0)   # chunk_first >= chunk_step
+    assert L.pt_config_pixels(C.byref(bad)) == 0

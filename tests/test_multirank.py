@@ -35,6 +35,18 @@ def _worker(rank, world, port, w, h, spp, seed, out_dir):
         img, cnt, _ = ptlib.oracle_render(sc, w, h, spp, seed, idx_begin=b, idx_end=e, threads=2)
         local = torch.from_numpy(img[b:e].copy())
         full = pkg.gather_bands(local, npix, rank, world, dist)
+        # the interleaved partition bench.py uses: rank r owns chunks r, r+world, ... (chunk = one row here)
+        counts, index = pkg.chunk_owner_map(npix, world, w)
+        mine = np.zeros((npix, 3), dtype=np.float32)
+        n_chunks = (npix + w - 1) // w
+        for c in range(rank, n_chunks, world):
+            lo, hi = c * w, min((c + 1) * w, npix)
+            part, _, _ = ptlib.oracle_render(sc, w, h, spp, seed, idx_begin=lo, idx_end=hi, threads=2)
+            mine[lo:hi] = part[lo:hi]
+        local2 = torch.from_numpy(mine[index[rank].numpy()].copy())
+        assert local2.shape[0] == counts[rank]
+        full2 = pkg.gather_chunks(local2, npix, rank, world, w, dist)
+        assert torch.equal(full2, full)
         total = torch.tensor([cnt.ray_bounces], dtype=torch.int64)
         dist.all_reduce(total)
         np.save(os.path.join(out_dir, "rank%d.npy" % rank), full.numpy())
