@@ -82,7 +82,7 @@ constexpr int32_t kNoBvh = 0x7fffffff;
 constexpr uint32_t kNoTri = 0x7fffffffu;
 constexpr uint32_t kBvhStack = 24;          // per-lane traversal stack entries (LDS; u16 each when nodes are staged)
 constexpr uint32_t kBvhMinTris = 16;        // meshes with fewer triangles are scanned linearly
-constexpr uint32_t kBvhMaxLdsNodes = 1024;  // 64 KiB of nodes at most are staged in LDS
+constexpr uint32_t kBvhMaxLdsNodes = 512;   // 32 KiB of nodes at most are staged in LDS (+ 24 KiB of stacks < 64 KiB)
 
 // per-object material record, gathered per lane in shade
 struct alignas(16) MatRec {

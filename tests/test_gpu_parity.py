@@ -502,3 +502,67 @@ def test_interleaved_chunks_equal_whole_frame(gpu):
     assert L.pt_config_pixels(C.byref(bad)) == 0
     bad = PtConfig(w, h, spp, 0, 12, 0, 0, 0, 0, 8, 2, 2, 0)   # chunk_first >= chunk_step
     assert L.pt_config_pixels(C.byref(bad)) == 0
+
+
+def test_large_mesh_bvh_in_global_memory(gpu):
+    """A 3 968-triangle tessellated sphere (2 000 BVH nodes: more than the LDS budget, so the nodes stay in global
+    memory and the traversal stack is the u32 form) next to a 200-triangle one (nodes in LDS), glass and diffuse,
+    inside an emissive enclosure: ray-by-ray hits and a small frame against the oracle's linear scan."""
+    L, ctx = gpu
+    O = ptlib.oracle()
+
+    def uv_sphere(radius, steps):
+        tris = []
+        for i in range(steps):
+            t1, t2 = np.pi * i / steps, np.pi * (i + 1) / steps
+            for j in range(2 * steps):
+                p1, p2 = 2 * np.pi * j / (2 * steps), 2 * np.pi * (j + 1) / (2 * steps)
+                P = lambda t, p: (radius * np.sin(t) * np.cos(p), radius * np.cos(t), radius * np.sin(t) * np.sin(p))
+                a, b, c, d = P(t1, p1), P(t2, p1), P(t2, p2), P(t1, p2)
+                if i == 0:
+                    tris.append((a, c, d))
+                elif i + 1 == steps:
+                    tris.append((a, b, c))
+                else:
+                    tris.append((a, b, d))
+                    tris.append((b, c, d))
+        return [ptlib.make_tri(*t) for t in tris]
+
+    big, small = uv_sphere(1.0, 32), uv_sphere(0.6, 8)
+    assert len(big) == 3968 and len(small) == 224
+    cam = ptlib.make_camera((0, 0, 6), (0, 0, -1))
+    objs = [ptlib.make_sphere((0, 0, 0), 20.0, (0.6, 0.6, 0.6), (0.4, 0.4, 0.4), "Diffuse"),
+            ptlib.make_mesh((-1.1, 0, 0), (0.9, 0.9, 0.9), (0, 0, 0), "Refract", 0, len(big), (0, 0, 0), 1.01),
+            ptlib.make_mesh((1.0, 0.2, 0.5), (0.9, 0.3, 0.3), (0, 0, 0), "Diffuse", len(big), len(small), (0, 0, 0), 0.61)]
+    sc = ptlib.Scene("tess", cam, objs, big + small)
+    set_scene(gpu, sc)
+    rng = np.random.default_rng(4)
+    n = 60000
+    o = rng.uniform(-3, 3, size=(n, 3)).astype(np.float32)
+    tgt = rng.normal(size=(n, 3)).astype(np.float32) * 0.8 + np.array([[-1.1, 0, 0]], np.float32) * (rng.random((n, 1)) < 0.6)
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d = np.ascontiguousarray(d.astype(np.float32))
+    o = np.ascontiguousarray(o)
+
+    def run(fn, handle):
+        t = np.zeros(n, np.float32)
+        oid = np.zeros(n, np.int32)
+        tid = np.zeros(n, np.int32)
+        rc = fn(handle, _np_f(o), _np_f(d), n, _np_f(t), oid.ctypes.data_as(ptlib.i32p),
+                tid.ctypes.data_as(ptlib.i32p), None, None)
+        return rc, t, oid, tid
+
+    rc, t, oid, tid = run(L.pt_ctx_intersect, ctx)
+    assert rc == 0, L.pt_last_error()
+    ps = sc.pto()
+    _, t0, oid0, tid0 = run(O.pto_intersect_batch, C.byref(ps))
+    assert (oid0 == 1).mean() > 0.2 and (oid0 == 2).mean() > 0.01
+    assert np.array_equal(oid, oid0) and np.array_equal(tid, tid0)
+    assert np.array_equal(t.view(np.uint32), t0.view(np.uint32))
+    w, h, spp = 40, 30, 2
+    want, cnt, _ = ptlib.oracle_render(sc, w, h, spp, 2)
+    for backend in (0, 1):
+        got, st = gpu_render(gpu, sc, w, h, spp, 2, backend)
+        assert st.ray_bounces == cnt.ray_bounces
+        assert float(np.abs(got - want).max()) <= TOL
