@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--backend", default="wavefront", choices=["wavefront", "megakernel"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=16)
+    ap.add_argument("--cpu-spp", type=int, default=128)  # ~15-20 s of CPU work on 16 host cores
     args = ap.parse_args()
 
     import torch
