@@ -1,0 +1,54 @@
+"""The C++ host (`ptrace <spp> <res_y> <scene>`, the reference's dead cmd_render.rs UX) end to end on the GPU:
+scene lookup by id and by index, width = res_y*3/2, P3 file + latest.ppm symlink, pixels = the oracle's frame."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import ptlib
+
+pytestmark = pytest.mark.gpu
+CLI = os.path.join(ptlib.PKG, "ptrace")
+
+
+def read_ppm(path):
+    data = open(path).read()
+    head, body = data.split("255\n", 1)
+    lines = head.split("\n")
+    assert lines[0] == "P3"
+    w, h = [int(v) for v in lines[3].split()]
+    vals = np.array(body.split(), dtype=np.int64).reshape(h * w, 3)
+    return lines, w, h, vals
+
+
+@pytest.mark.parametrize("scene_arg,sid", [("cornell", "cornell"), ("1", "cornell")])  # index 1 of the sorted listing
+def test_cli_matches_oracle(tmp_path, scene_arg, sid):
+    if not os.path.exists(CLI):
+        pytest.skip("CLI not built")
+    out = tmp_path / "out"
+    r = subprocess.run([CLI, "6", "24", scene_arg, "--root", ptlib.ROOT, "--seed", "3", "--out", str(out), "--gpus", "2"],
+                       cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Rendering scene %s (11 objects), 6 samples per pixel, 36x24 resolution" % sid in r.stdout
+    files = [f for f in os.listdir(out) if f.endswith(".ppm")]
+    assert len(files) == 1 and files[0].endswith("-scene-%s-spp6-res24-.ppm" % sid)
+    assert os.path.islink(tmp_path / "latest.ppm")
+    lines, w, h, vals = read_ppm(str(out / files[0]))
+    assert (w, h) == (36, 24) and lines[1] == "# samplesPerPixel: 6, resolution_y: 24, scene_id: %s" % sid
+    sc = ptlib.load_scene_py(ptlib.scene_path(sid))
+    img, _, _ = ptlib.oracle_render(sc, 36, 24, 6, 3)
+    O = ptlib.oracle()
+    want = np.array([[O.pto_to_int_with_gamma_correction(float(v)) for v in px] for px in img[::-1]], dtype=np.int64)
+    diff = np.abs(vals - want)
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.002  # 1e-7 radiance differences may flip a rounding
+
+
+def test_cli_errors(tmp_path):
+    if not os.path.exists(CLI):
+        pytest.skip("CLI not built")
+    assert subprocess.run([CLI], capture_output=True).returncode == 1
+    r = subprocess.run([CLI, "4", "16", "no-such-scene", "--root", ptlib.ROOT], capture_output=True, text=True)
+    assert r.returncode == 1 and "cannot load scene" in r.stderr
+    r = subprocess.run([CLI, "4", "16", "99", "--root", ptlib.ROOT], capture_output=True, text=True)
+    assert r.returncode == 1 and "out of range" in r.stderr
