@@ -332,21 +332,31 @@ __host__ __device__ inline size_t bvh_lds_bytes(const DevScene &S, uint32_t bloc
 
 // One object of a pair: the tail of SceneObjectData::intersect (mod.rs:261-280) + intersect_scene's replace
 // rule (mod.rs:649), given the sphere discriminant arithmetic (b, det) that was done packed for both halves.
-template <bool BVH>
+//   EXACT_GATES = false is the speculative pass: a mesh is admitted when its bounding-sphere discriminant is
+//   non-negative - a necessary condition of the gate that needs no square root - instead of the full
+//   intersect_sphere(...).is_some() (mod.rs:267-273).  intersect_scene_dev verifies the winner afterwards.
+template <bool BVH, bool EXACT_GATES>
 __device__ __forceinline__ void consider_object(const DevScene &S, const ObjPairRec &ob, int hf, float b, float det,
                                                 vec3 o, vec3 d, uint4 *lds, float &best_t, int32_t &best_id) {
     const float eps = 1e-4f;
-    const float sq = f_sqrt(det);  // NaN when det < 0: both comparisons below are then false
-    const float t0 = b - sq, t1 = b + sq;
-    const bool near_ok = t0 >= eps, far_ok = t1 >= eps;
-    const bool sph_hit = !(det < 0.0f) && (near_ok || far_ok);
+    bool sph_hit;
     if (ob.kind[hf] == kKindSphere) {
+        const float sq = f_sqrt(det);  // NaN when det < 0: both comparisons below are then false
+        const float t0 = b - sq, t1 = b + sq;
+        const bool near_ok = t0 >= eps, far_ok = t1 >= eps;
+        sph_hit = !(det < 0.0f) && (near_ok || far_ok);
         const float t = near_ok ? t0 : t1;
         if (sph_hit && t < best_t) {
             best_t = t;
             best_id = (int32_t)ob.obj[hf];
         }
         return;
+    }
+    if (EXACT_GATES) {
+        const float sq = f_sqrt(det);
+        sph_hit = !(det < 0.0f) && ((b - sq) >= eps || (b + sq) >= eps);
+    } else {
+        sph_hit = !(det < 0.0f);
     }
     // bounding-sphere gate (mod.rs:267-273): skip the triangle list when no lane passes
     if (__builtin_amdgcn_ballot_w64(sph_hit) == 0ull) return;
@@ -388,8 +398,8 @@ __device__ __forceinline__ void consider_object(const DevScene &S, const ObjPair
 // mod.rs:637,649); inside a mesh the first triangle in list order wins ties (mod.rs:598).
 // `best` starts at +inf instead of Option::None: identical for every finite, non-NaN distance.
 // BVH = false compiles the traversal out (scenes without a BVH mesh keep the small register footprint).
-template <bool BVH>
-__device__ __forceinline__ HitRec intersect_scene_dev(const DevScene &S, vec3 o, vec3 d, uint4 *lds) {
+template <bool BVH, bool EXACT_GATES>
+__device__ __forceinline__ HitRec scan_scene(const DevScene &S, vec3 o, vec3 d, uint4 *lds) {
     float best_t = __builtin_inff();
     int32_t best_id = -1;
     const f32x2 ox2 = splat2(o.x), oy2 = splat2(o.y), oz2 = splat2(o.z);
@@ -401,12 +411,35 @@ __device__ __forceinline__ HitRec intersect_scene_dev(const DevScene &S, vec3 o,
         const f32x2 opx = ld2(ob.cx) - ox2, opy = ld2(ob.cy) - oy2, opz = ld2(ob.cz) - oz2;
         const f32x2 b = (opx * dx2 + opy * dy2) + opz * dz2;
         const f32x2 det = (b * b - ((opx * opx + opy * opy) + opz * opz)) + ld2(ob.rr);
-        consider_object<BVH>(S, ob, 0, b[0], det[0], o, d, lds, best_t, best_id);
-        consider_object<BVH>(S, ob, 1, b[1], det[1], o, d, lds, best_t, best_id);
+        consider_object<BVH, EXACT_GATES>(S, ob, 0, b[0], det[0], o, d, lds, best_t, best_id);
+        consider_object<BVH, EXACT_GATES>(S, ob, 1, b[1], det[1], o, d, lds, best_t, best_id);
     }
     HitRec h;
     h.t = best_t;
     h.id = best_id;
+    return h;
+}
+
+// Speculate on the gates, verify the winner.  The speculative scan admits a superset of the meshes the reference
+// admits (discriminant >= 0 is necessary for intersect_sphere to return Some), so its winner is the minimum over a
+// superset of the reference's candidates under the same order and tie rules: if that winner is itself a reference
+// candidate - a sphere, or a triangle of a mesh whose exact gate passes - it IS the reference's winner.  Only the
+// winner's own gate has to be evaluated exactly (one square root per ray instead of one per mesh); when it fails for
+// some lane (rounding at the rim of a bounding sphere) the wave repeats the scan with exact gates.
+template <bool BVH>
+__device__ __forceinline__ HitRec intersect_scene_dev(const DevScene &S, vec3 o, vec3 d, uint4 *lds) {
+    HitRec h = scan_scene<BVH, false>(S, o, d, lds);
+    bool suspect = false;
+    if (h.id >= (int32_t)S.n_objs) {
+        const uint32_t owner = S.tri_shade[h.id - (int32_t)S.n_objs].owner;
+        const ObjRec g = S.objs[owner];  // per-lane gather: the winner's bounding sphere
+        const vec3 op = mk(g.cx, g.cy, g.cz) - o;
+        const float b = dot(op, d);
+        const float det = b * b - dot(op, op) + g.rr;
+        const float sq = f_sqrt(det);
+        suspect = !(!(det < 0.0f) && ((b - sq) >= 1e-4f || (b + sq) >= 1e-4f));
+    }
+    if (__builtin_amdgcn_ballot_w64(suspect) != 0ull) h = scan_scene<BVH, true>(S, o, d, lds);
     return h;
 }
 

@@ -402,6 +402,17 @@ def test_edge_scenes(gpu):
             ptlib.make_sphere((0, 0, 0), 1.0, (0.9, 0.9, 0.9), (0, 0, 0), "Refract"),
             ptlib.make_sphere((2, 0, 0), 1.0, (0.9, 0.9, 0.9), (0, 0, 0), "Specular")], []),
     }
+    # an inline mesh whose stored bounding sphere does not enclose it (the reference uses the stored sphere
+    # verbatim, mod.rs:315): the quad at z = 0 is only "seen" by rays that also hit the small sphere placed (a) in
+    # front of it, (b) behind the camera - there the line hits the sphere but intersect_sphere returns None, which
+    # is exactly the case the speculative gate of the device code has to catch and redo
+    quad = [ptlib.make_tri((-2, -2, 0), (2, -2, 0), (2, 2, 0)), ptlib.make_tri((-2, -2, 0), (2, 2, 0), (-2, 2, 0))]
+    cases["lying_sphere_front"] = ptlib.Scene("l1", cam, [
+        ptlib.make_sphere((0, 0, 0), 30.0, (0.5, 0.5, 0.5), (0.2, 0.2, 0.2), "Diffuse"),
+        ptlib.make_mesh((0, 0, 0), (0.9, 0.2, 0.2), (0.1, 0, 0), "Diffuse", 0, 2, (0.3, 0.2, 1.0), 0.7)], quad)
+    cases["lying_sphere_behind"] = ptlib.Scene("l2", cam, [
+        ptlib.make_sphere((0, 0, 0), 30.0, (0.5, 0.5, 0.5), (0.2, 0.2, 0.2), "Diffuse"),
+        ptlib.make_mesh((0, 0, 0), (0.9, 0.2, 0.2), (0.1, 0, 0), "Diffuse", 0, 2, (0.0, 0.0, 9.0), 3.0)], quad)
     for name, sc in cases.items():
         for (w, h, spp) in ((1, 1, 5), (33, 17, 6)):
             want, cnt, _ = ptlib.oracle_render(sc, w, h, spp, 21)
