@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--rays-per-pass", type=int, default=0)
     ap.add_argument("--backend", default="wavefront", choices=["wavefront", "megakernel"])
+    ap.add_argument("--pipelines", type=int, default=1,
+                    help="concurrent wavefront pipelines per GPU (opt-in; per-kernel roofline is only reported for 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=128)  # ~15-20 s of CPU work on 16 host cores
@@ -141,23 +143,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step(backend, profile):
+    def step(backend, profile, pipelines=1):
         ctx.set_profiling(profile)
         st = ctx.render(local.data_ptr(), W, H, spp, seed=args.seed, backend=backend, chunks=chunks,
-                        rays_per_pass=args.rays_per_pass)
+                        rays_per_pass=args.rays_per_pass, pipelines=pipelines)
         full = pkg.gather_chunks(local if dist_backend == "nccl" else local.cpu(), npix, rank, world, chunk, dist)
         return st, full
 
-    def timed(backend, steps, warmup, profile):
+    def timed(backend, steps, warmup, profile, pipelines=1):
         for _ in range(warmup):
-            step(backend, profile)
+            step(backend, profile, pipelines)
         barrier()
         t0 = time.perf_counter()
         bounces = isect_rays = 0
         isect_ms = 0.0
         launches = 0
         for _ in range(steps):
-            st, full = step(backend, profile)
+            st, full = step(backend, profile, pipelines)
             bounces += st.ray_bounces
             isect_rays += st.intersect_rays
             isect_ms += st.ms_intersect
@@ -173,7 +175,8 @@ def main():
             bounces = int(b.item())
         return dict(dt=dt, bounces=bounces, isect_rays=isect_rays, isect_ms=isect_ms, launches=launches, image=full)
 
-    main_run = timed(args.backend, args.steps, args.warmup, profile=(args.backend == "wavefront"))
+    main_run = timed(args.backend, args.steps, args.warmup, profile=(args.backend == "wavefront" and args.pipelines == 1),
+                     pipelines=args.pipelines)
     value = main_run["bounces"] / main_run["dt"]
     out = {
         "metric": "ray_bounces_per_sec",
@@ -242,6 +245,14 @@ def main():
         out["variants"] = {other: {"value": v["bounces"] / v["dt"], "unit": "ray-bounces/s",
                                    "ms_per_step": 1e3 * v["dt"] / max(1, min(args.steps, 2)),
                                    "image_identical_to_main_backend": same}}
+        if args.backend == "wavefront" and args.pipelines == 1:
+            # opt-in mode: 2 independent wavefront pipelines on 2 streams of this GPU (VALU-bound intersect of one
+            # overlaps HBM-bound shade of another); not the headline because per-kernel timings lose their meaning
+            v3 = timed("wavefront", max(1, min(args.steps, 2)), 1, profile=False, pipelines=2)
+            out["variants"]["wavefront_2_concurrent_pipelines"] = {
+                "value": v3["bounces"] / v3["dt"], "unit": "ray-bounces/s",
+                "ms_per_step": 1e3 * v3["dt"] / max(1, min(args.steps, 2)),
+                "image_identical_to_main_backend": bool(torch.equal(v3["image"], main_run["image"]))}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(W, H, args.seed, args.cpu_spp)
     if rank == 0:

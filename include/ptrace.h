@@ -51,6 +51,13 @@ extern "C" {
 
 /* pt_config.flags */
 #define PT_FLAG_NO_BVH 1u /* meshes are scanned triangle by triangle as the reference does (mod.rs:558) */
+/* Concurrent pipelines (wavefront backend): bits 8..11 of flags = n (2..8).  The call's pixels are dealt chunk by
+ * chunk to n independent wavefront pipelines on n HIP streams of the same GPU, so the VALU-bound intersect kernels
+ * of one pipeline overlap the HBM-bound shade kernels of another (cornell: +15 % with 2; 3 or more only help when
+ * the runtime exposes enough hardware queues, GPU_MAX_HW_QUEUES=8).  Same
+ * image, bit for bit.  Per-kernel timings (pt_stats.ms_intersect, rocprof) then describe kernels that share the
+ * machine, which is why it is opt-in: the default single pipeline keeps per-kernel roofline numbers meaningful. */
+#define PT_FLAG_PIPELINES(n) (((uint32_t)(n) & 15u) << 8)
 
 /* CameraData — src/render/mod.rs:162-176.  `direction` is used as stored (not renormalised). */
 typedef struct pt_camera {

@@ -80,6 +80,10 @@ struct pt_ctx {
     // state of the frame being rendered (for pt_ctx_snapshot from the progress callback)
     uint32_t live_npix = 0, live_spp_issued = 0;
     hipStream_t live_stream = nullptr;
+    // concurrent pipelines (PT_FLAG_PIPELINES): child contexts that borrow this context's scene tables
+    std::vector<pt_ctx *> pipes;
+    std::vector<DevBuf<float>> pipe_out;
+    bool borrowed_scene = false;
 };
 
 namespace {
@@ -433,6 +437,9 @@ int pt_ctx_create(int device, pt_ctx **out) {
 
 void pt_ctx_destroy(pt_ctx *c) {
     if (!c) return;
+    for (pt_ctx *p : c->pipes) pt_ctx_destroy(p);  // children own their queues, not the scene tables
+    c->pipes.clear();
+    for (auto &b : c->pipe_out) b.release();
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
@@ -550,6 +557,82 @@ int pt_ctx_set_profiling(pt_ctx *c, int enabled) {
     return PT_OK;
 }
 
+// n concurrent wavefront pipelines over the pixels of one call (PT_FLAG_PIPELINES)
+static int render_pipelined(pt_ctx *c, const pt_config *cfg, uint32_t n, uint32_t ib, uint32_t ie, float *d_out,
+                            const volatile uint8_t *cancel, pt_progress_fn cb, void *user, pt_stats *stats) {
+    // the caller's partition of [ib, ie): chunks first, first+step, ... of C pixels (whole band: rows of the image)
+    const uint32_t C = cfg->chunk_step > 1u ? cfg->chunk_pixels : cfg->width;
+    const uint32_t first = cfg->chunk_step > 1u ? cfg->chunk_first : 0u;
+    const uint32_t step = cfg->chunk_step > 1u ? cfg->chunk_step : 1u;
+    while (c->pipes.size() < n) {
+        pt_ctx *p = nullptr;
+        int rc = pt_ctx_create(c->device, &p);
+        if (rc) return rc;
+        p->borrowed_scene = true;
+        c->pipes.push_back(p);
+        c->pipe_out.emplace_back();
+    }
+    std::vector<pt_config> cfgs(n, *cfg);
+    std::vector<pt_stats> sts(n);
+    std::vector<int> rcs(n, PT_OK);
+    std::vector<std::string> errs(n);
+    std::vector<uint32_t> own(n, 0);
+    for (uint32_t j = 0; j < n; ++j) {
+        pt_ctx *p = c->pipes[j];
+        p->scene = c->scene;  // device pointers of the parent's scene tables (read-only)
+        p->cam = c->cam;
+        p->n_bvh_nodes = c->n_bvh_nodes;
+        p->has_scene = true;
+        p->profiling = c->profiling;
+        cfgs[j].flags &= ~PT_FLAG_PIPELINES(15);
+        cfgs[j].idx_begin = ib;
+        cfgs[j].idx_end = ie;
+        cfgs[j].chunk_pixels = C;
+        cfgs[j].chunk_first = first + step * j;
+        cfgs[j].chunk_step = step * n;
+        own[j] = owned_pixels(&cfgs[j], ib, ie);
+        int rc = c->pipe_out[j].ensure((size_t)own[j] * 3);
+        if (rc) return rc;
+    }
+    std::vector<std::thread> th;
+    for (uint32_t j = 0; j < n; ++j) {
+        if (own[j] == 0u) continue;
+        th.emplace_back([&, j]() {
+            rcs[j] = pt_ctx_render(c->pipes[j], &cfgs[j], c->pipe_out[j].p, nullptr, cancel, j == 0 ? cb : nullptr, user,
+                                   &sts[j]);
+            if (rcs[j] != PT_OK) errs[j] = g_last_error;
+        });
+    }
+    for (auto &t : th) t.join();
+    HIP_TRY(hipSetDevice(c->device));
+    int worst = PT_OK;
+    for (uint32_t j = 0; j < n; ++j) {
+        if (own[j] == 0u) continue;
+        if (rcs[j] != PT_OK && rcs[j] != PT_CANCELLED) {
+            set_error("pipeline " + std::to_string(j) + ": " + errs[j]);
+            return rcs[j];
+        }
+        if (rcs[j] == PT_CANCELLED) worst = PT_CANCELLED;
+        // pipeline j's k-th chunk is the call's (k*n + j)-th chunk
+        launch_scatter_chunks(c->stream, c->pipe_out[j].p, d_out, own[j], C, n, j);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (stats) {
+        for (uint32_t j = 0; j < n; ++j) {
+            stats->ray_bounces += sts[j].ray_bounces;
+            stats->samples += sts[j].samples;
+            stats->intersect_rays += sts[j].intersect_rays;
+            stats->intersect_launches += sts[j].intersect_launches;
+            stats->passes += sts[j].passes;
+            stats->ms_device = sts[j].ms_device > stats->ms_device ? sts[j].ms_device : stats->ms_device;
+            stats->ms_intersect += sts[j].ms_intersect;
+        }
+    }
+    if (worst == PT_CANCELLED) set_error("cancelled");
+    return worst;
+}
+
 int pt_ctx_render(pt_ctx *c, const pt_config *cfg, void *d_out_rgb, void *hip_stream, const volatile uint8_t *cancel,
                   pt_progress_fn cb, void *user, pt_stats *stats) {
     if (!c || !d_out_rgb) {
@@ -564,6 +647,20 @@ int pt_ctx_render(pt_ctx *c, const pt_config *cfg, void *d_out_rgb, void *hip_st
     int rc = check_cfg(cfg, &ib, &ie);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
+    const uint32_t n_pipes = (cfg->flags >> 8) & 15u;
+    if (n_pipes > 1u && cfg->backend == PT_BACKEND_WAVEFRONT) {
+        if (n_pipes > 8u) {
+            set_error("at most 8 concurrent pipelines");
+            return PT_ERR_INVALID;
+        }
+        if (stats) memset(stats, 0, sizeof *stats);
+        const double t0p = now_ms();
+        c->scene.n_bvh_nodes = (cfg->flags & PT_FLAG_NO_BVH) ? 0u : c->n_bvh_nodes;
+        rc = render_pipelined(c, cfg, n_pipes, ib, ie, (float *)d_out_rgb, cancel, cb, user, stats);
+        c->scene.n_bvh_nodes = c->n_bvh_nodes;
+        if (stats) stats->ms_total = now_ms() - t0p;
+        return rc;
+    }
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     const FrameParams F = make_frame(c, cfg, ib, ie);
     if (stats) memset(stats, 0, sizeof *stats);

@@ -26,6 +26,8 @@ void launch_intersect(hipStream_t st, uint32_t K, const DevScene &S, const RayQu
 void launch_shade(hipStream_t st, uint32_t K, const DevScene &S, const FrameParams &F, const RayQueue &qin,
                   const RayQueue &qout, const float2 *hit, const uint32_t *cnt_in, uint32_t *cnt_out, uint32_t cap,
                   unsigned long long *acc, uint32_t *flags, uint32_t m, uint32_t s0);
+void launch_scatter_chunks(hipStream_t st, const float *src, float *dst, uint32_t npix, uint32_t C, uint32_t n,
+                           uint32_t j);
 void launch_resolve(hipStream_t st, const unsigned long long *acc, float *out, uint32_t npix, uint32_t spp);
 void launch_mega(hipStream_t st, uint32_t grid, const DevScene &S, const FrameParams &F, unsigned long long *acc,
                  uint32_t chunk_spp, uint32_t n_chunks, unsigned long long *total_rays);

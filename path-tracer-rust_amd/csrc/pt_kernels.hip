@@ -204,6 +204,18 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const unsigned long long *__
     }
 }
 
+// pipeline j of n wrote its chunks back to back; its k-th chunk is the call's (k*n + j)-th chunk
+__global__ __launch_bounds__(kBlock) void k_scatter_chunks(const float *__restrict__ src, float *__restrict__ dst,
+                                                           uint32_t npix, uint32_t C, uint32_t n, uint32_t j) {
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= npix) return;
+    const uint32_t k = p / C, w = p - k * C;
+    const size_t at = ((size_t)k * n + j) * C + w;
+    dst[at * 3 + 0] = src[(size_t)p * 3 + 0];
+    dst[at * 3 + 1] = src[(size_t)p * 3 + 1];
+    dst[at * 3 + 2] = src[(size_t)p * 3 + 2];
+}
+
 // ------------------------------------------------------------------------------------------------
 // Persistent megakernel: one lane = one (pixel, sample chunk); the lane walks its samples one after the
 // other and each loop trip advances every live path of the wave by one bounce, so the intersect and
@@ -385,6 +397,10 @@ void launch_shade(hipStream_t st, uint32_t K, const DevScene &S, const FramePara
     P.chunk_step = F.chunk_step;
     hipLaunchKernelGGL(k_shade, dim3(K), dim3(kBlock), lds, st, S, P, qin, qout, hit, cnt_in, cnt_out, cap, acc,
                        flags, m);
+}
+void launch_scatter_chunks(hipStream_t st, const float *src, float *dst, uint32_t npix, uint32_t C, uint32_t n,
+                           uint32_t j) {
+    hipLaunchKernelGGL(k_scatter_chunks, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, st, src, dst, npix, C, n, j);
 }
 void launch_resolve(hipStream_t st, const unsigned long long *acc, float *out, uint32_t npix, uint32_t spp) {
     hipLaunchKernelGGL(k_resolve, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, st, acc, out, npix, spp);

@@ -577,3 +577,39 @@ def test_large_mesh_bvh_in_global_memory(gpu):
         got, st = gpu_render(gpu, sc, w, h, spp, 2, backend)
         assert st.ray_bounces == cnt.ray_bounces
         assert float(np.abs(got - want).max()) <= TOL
+
+
+def test_concurrent_pipelines_same_image(gpu):
+    """PT_FLAG_PIPELINES(n): n wavefront pipelines on n streams share the call's pixels chunk by chunk.  Same image
+    and bounce count as the single pipeline, also on top of a rank's own chunking and with a partial last chunk."""
+    L, ctx = gpu
+    sc = ptlib.load_scene_py(ptlib.scene_path("cornell"))
+    set_scene(gpu, sc)
+    w, h, spp = 50, 33, 6
+    npix = w * h
+    whole, st = gpu_render(gpu, sc, w, h, spp, 12)
+
+    def render(cfg):
+        own = L.pt_config_pixels(C.byref(cfg))
+        d_out = C.c_void_p()
+        assert L.pt_device_malloc(0, own * 12, C.byref(d_out)) == 0
+        s2 = PtStats()
+        rc = L.pt_ctx_render(ctx, C.byref(cfg), d_out, None, None, None, None, C.byref(s2))
+        assert rc == 0, L.pt_last_error()
+        part = np.zeros((own, 3), dtype=np.float32)
+        assert L.pt_device_download(0, part.ctypes.data_as(C.c_void_p), d_out, own * 12) == 0
+        L.pt_device_free(0, d_out)
+        return part, s2.ray_bounces
+
+    for n in (2, 3, 5, 8):  # rays_per_pass kept small: every pipeline allocates its own ray streams
+        img, nb = render(PtConfig(w, h, spp, 0, 12, 0, 0, 4000, n << 8))
+        assert np.array_equal(img, whole) and nb == st.ray_bounces, n
+    # inside a rank's partition: rank 1 of 3 with 64-pixel chunks, 2 pipelines
+    cfg = PtConfig(w, h, spp, 0, 12, 0, 0, 4000, 2 << 8, 64, 1, 3, 0)
+    img, _ = render(cfg)
+    idx = np.arange(npix)
+    mine = idx[(idx // 64) % 3 == 1]
+    assert np.array_equal(img, whole[mine])
+    # a band, 3 pipelines
+    img, _ = render(PtConfig(w, h, spp, 0, 12, 130, 1500, 4000, 3 << 8))
+    assert np.array_equal(img, whole[130:1500])
