@@ -227,6 +227,12 @@ int pt_scene_load_ex(const char *path, const char *base_dir, uint32_t flags, pt_
  * bounding_sphere / bounding_box). */
 int pt_scene_save(const pt_scene *s, const char *path);
 int pt_scene_set_camera(pt_scene *s, const pt_camera *cam);
+/* setup_scenes (src/render/scenes.rs:43-318): the scenes the reference builds in code and saves when scenes/ holds
+ * no *.json (load_scene_ids, scenes.rs:28-38) - "single-sphere", "cartesian", "two-spheres", "three-spheres",
+ * "cornell", "mesh" in that order.  `base_dir` is where "mesh" finds meshes/mctri.off. */
+uint32_t pt_builtin_scene_count(void);
+const char *pt_builtin_scene_id(uint32_t i);
+int pt_scene_builtin(const char *id, const char *base_dir, pt_scene **out);
 void pt_scene_free(pt_scene *s);
 const char *pt_scene_id(const pt_scene *s);
 const pt_camera *pt_scene_camera(const pt_scene *s);

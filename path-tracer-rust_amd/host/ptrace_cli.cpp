@@ -72,6 +72,18 @@ int main(int argc, char **argv) {
         usage();
         return 1;
     }
+    // load_scene_ids (scenes.rs:28-38): a scenes/ directory without any *.json is filled with the built-in scenes
+    if (scene_ids(root).empty()) {
+        mkdir((root + "/scenes").c_str(), 0777);
+        for (uint32_t i = 0; i < pt_builtin_scene_count(); ++i) {
+            const char *bid = pt_builtin_scene_id(i);
+            pt_scene *b = nullptr;
+            if (pt_scene_builtin(bid, root.c_str(), &b) != PT_OK ||
+                pt_scene_save(b, (root + "/scenes/" + bid + ".json").c_str()) != PT_OK)
+                fprintf(stderr, "Failed to save scene '%s': %s\n", bid, pt_last_error());
+            pt_scene_free(b);
+        }
+    }
     // SceneId::Int(i) -> nth scene of the listing, SceneId::String -> by id (cmd_render.rs:19-30)
     std::string id = scene_arg;
     char *endp = nullptr;

@@ -867,6 +867,195 @@ int pt_scene_save(const pt_scene *s, const char *path) {
     return PT_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The scenes the reference builds in code when scenes/ holds no *.json (setup_scenes, scenes.rs:43-318; written to
+// disk by load_scene_ids, scenes.rs:28-38).  Same values, same f32 arithmetic (e.g. the light's emission is
+// (0.98, 1, 0.9) * 0.9 evaluated in f32), expressed as tables.
+}  // extern "C"
+
+namespace {
+
+struct BuiltinSphere {
+    float pos[3], radius, color[3], emission[3];
+    uint32_t reflect;
+};
+struct BuiltinQuad {  // single_quad_mesh(size_x, size_y, axis, flip), scenes.rs:322-367
+    float pos[3], size_x, size_y;
+    int axis;
+    bool flip;
+    float color[3], emission[3];
+};
+
+constexpr float kBoxX = 2.6f, kBoxY = 2.0f, kBoxZ = 8.8f;  // BOX, scenes.rs:45-49
+
+void add_sphere(pt_scene &sc, const BuiltinSphere &b) {
+    pt_object o;
+    memset(&o, 0, sizeof o);
+    o.kind = PT_SPHERE;
+    memcpy(o.position, b.pos, 12);
+    o.radius = b.radius;
+    memcpy(o.color, b.color, 12);
+    memcpy(o.emission, b.emission, 12);
+    o.reflect_type = b.reflect;
+    sc.objects.push_back(o);
+    sc.desc.push_back(ObjDesc());
+}
+
+// two triangles over the rectangle [-size_x, size_x] x [-size_y, size_y] spanned by axes (axis+1)%3 and (axis+2)%3
+void add_quad(pt_scene &sc, const BuiltinQuad &q) {
+    float v[4][3];
+    const int i1 = (q.axis + 1) % 3, i2 = (q.axis + 2) % 3;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) {
+            float *p = v[2 * i + j];
+            p[0] = p[1] = p[2] = 0.0f;
+            p[i1] = i == 0 ? -q.size_x : q.size_x;
+            p[i2] = j == 0 ? -q.size_y : q.size_y;
+        }
+    static const int order[2][2][3] = {{{0, 2, 1}, {1, 2, 3}}, {{0, 1, 2}, {2, 1, 3}}};  // [flip][triangle][corner]
+    pt_triangle t[2];
+    for (int k = 0; k < 2; ++k) {
+        memcpy(t[k].a, v[order[q.flip][k][0]], 12);
+        memcpy(t[k].b, v[order[q.flip][k][1]], 12);
+        memcpy(t[k].c, v[order[q.flip][k][2]], 12);
+    }
+    pt_object o;
+    memset(&o, 0, sizeof o);
+    o.kind = PT_MESH;
+    memcpy(o.position, q.pos, 12);
+    memcpy(o.color, q.color, 12);
+    memcpy(o.emission, q.emission, 12);
+    o.reflect_type = PT_DIFFUSE;
+    o.tri_offset = (uint32_t)sc.triangles.size();
+    o.tri_count = 2;
+    pt::host::mesh_bounding_sphere(t, 2, o.bs_center, &o.bs_radius);  // Mesh::new, mod.rs:450-499
+    sc.triangles.push_back(t[0]);
+    sc.triangles.push_back(t[1]);
+    sc.objects.push_back(o);
+    ObjDesc d;
+    d.variant = 2;
+    sc.desc.push_back(d);
+}
+
+// the six walls and the ceiling light shared by "cornell" and "mesh" (scenes.rs:51-123)
+void add_cornell_box(pt_scene &sc) {
+    const float light = 0.9f;
+    const BuiltinQuad walls[7] = {
+        {{kBoxX, 0.0f, 0.0f}, kBoxY, kBoxZ, 0, true, {0.85f, 0.25f, 0.25f}, {0.0f, 0.0f, 0.0f}},    // right, red
+        {{-kBoxX, 0.0f, 0.0f}, kBoxY, kBoxZ, 0, false, {0.25f, 0.35f, 0.85f}, {0.0f, 0.0f, 0.0f}},  // left, blue
+        {{0.0f, kBoxY, 0.0f}, kBoxZ, kBoxX, 1, true, {0.8f, 0.8f, 0.8f}, {0.0f, 0.0f, 0.0f}},       // top
+        {{0.0f, -kBoxY, 0.0f}, kBoxZ, kBoxX, 1, false, {0.7f, 0.7f, 0.7f}, {0.0f, 0.0f, 0.0f}},     // bottom
+        {{0.0f, 0.0f, -kBoxZ}, kBoxX, kBoxY, 2, true, {0.95f, 0.95f, 0.95f}, {0.0f, 0.0f, 0.0f}},   // back
+        {{0.0f, 0.0f, kBoxZ}, kBoxX, kBoxY, 2, true, {0.05f, 0.05f, 0.05f}, {0.0f, 0.0f, 0.0f}},    // front
+        {{0.0f, kBoxY - 0.04f, 0.0f}, kBoxZ, kBoxX, 1, true, {0.98f, 1.0f, 0.9f},
+         {0.98f * light, 1.0f * light, 0.9f * light}},                                               // ceiling light
+    };
+    for (const BuiltinQuad &w : walls) add_quad(sc, w);
+}
+
+// CameraData::new (mod.rs:178-186): direction.normalize() = v * (1 / length) in glam
+pt_camera builtin_camera(float px, float py, float pz, float dx, float dy, float dz) {
+    pt_camera c;
+    c.position[0] = px;
+    c.position[1] = py;
+    c.position[2] = pz;
+    const float len = sqrtf((dx * dx + dy * dy) + dz * dz);
+    const float inv = 1.0f / len;
+    c.direction[0] = dx * inv;
+    c.direction[1] = dy * inv;
+    c.direction[2] = dz * inv;
+    c.focal_length = 0.035f;
+    c.sensor_width = 0.036f;
+    c.aspect_ratio = 3.0f / 2.0f;
+    return c;
+}
+
+const char *const kBuiltinIds[] = {"single-sphere", "cartesian", "two-spheres", "three-spheres", "cornell", "mesh"};
+
+}  // namespace
+
+extern "C" {
+
+uint32_t pt_builtin_scene_count(void) { return (uint32_t)(sizeof kBuiltinIds / sizeof kBuiltinIds[0]); }
+
+const char *pt_builtin_scene_id(uint32_t i) { return i < pt_builtin_scene_count() ? kBuiltinIds[i] : nullptr; }
+
+int pt_scene_builtin(const char *id, const char *base_dir, pt_scene **out) {
+    if (!id || !out) {
+        pt::set_error("NULL argument");
+        return PT_ERR_INVALID;
+    }
+    *out = nullptr;
+    std::unique_ptr<pt_scene> sc(new pt_scene());
+    sc->id = id;
+    sc->camera = builtin_camera(0.0f, -kBoxY + 1.8f, kBoxZ - 1.0f, 0.0f, -0.06f, -1.0f);  // default_camera
+    const std::string name = id;
+    const uint32_t D = PT_DIFFUSE;
+    if (name == "single-sphere") {
+        add_sphere(*sc, {{0, 0, 0}, 1.0f, {1, 1, 1}, {0.98f * 15.0f, 15.0f, 0.9f * 15.0f}, D});
+    } else if (name == "cartesian") {
+        add_sphere(*sc, {{0, 0, 0}, 0.3f, {0.9f, 0.9f, 0.9f}, {0, 0, 0}, D});
+        add_sphere(*sc, {{1, 0, 0}, 0.3f, {0.8f, 0, 0}, {0, 0, 0}, D});
+        add_sphere(*sc, {{-1, 0, 0}, 0.3f, {0, 0, 0.8f}, {0, 0, 0}, D});
+        add_sphere(*sc, {{0, 1, 0}, 0.3f, {0, 0.8f, 0}, {0, 0, 0}, D});
+    } else if (name == "two-spheres") {
+        add_sphere(*sc, {{0, 0, 0}, 1.0f, {1, 0, 0}, {0, 0, 0}, D});
+        add_sphere(*sc, {{0, 0, 10}, 1.0f, {0, 0, 0}, {10, 10, 10}, D});
+    } else if (name == "three-spheres") {
+        add_sphere(*sc, {{0, 0, -3}, 1.0f, {1.0f, 0.2f, 0.2f}, {0, 0, 0}, D});
+        add_sphere(*sc, {{4, 2, 0}, 1.0f, {0, 0, 0}, {20, 10, 10}, D});
+        add_sphere(*sc, {{-6, -2, 0}, 1.0f, {0, 0, 0}, {5, 9, 20}, D});
+    } else if (name == "cornell") {
+        const float y = -kBoxY + 0.8f;
+        add_sphere(*sc, {{-1.3f, y, -1.3f}, 0.8f, {0.999f, 0.999f, 0.999f}, {0, 0, 0}, PT_SPECULAR});
+        add_sphere(*sc, {{1.3f, y, -0.2f}, 0.8f, {0.999f, 0.999f, 0.999f}, {0, 0, 0}, PT_REFRACT});
+        add_sphere(*sc, {{0.08f, y, -0.8f}, 0.5f, {0.999f, 0.999f, 0.999f}, {0.98f * 2.0f, 1.0f * 2.0f, 0.9f * 2.0f}, D});
+        add_sphere(*sc, {{-0.08f, y, 0.7f}, 0.5f, {0.4f, 0.9f, 0.49f}, {0, 0, 0}, D});
+        add_cornell_box(*sc);
+    } else if (name == "mesh") {
+        const char *rel = "meshes/mctri.off";
+        const float scale = 0.16f;
+        std::vector<pt_triangle> tl;
+        std::string err;
+        int rc = load_off_impl(std::string(base_dir ? base_dir : ".") + "/" + rel, scale, 0u, tl, err);
+        if (rc) {
+            pt::set_error("builtin scene `mesh`: " + err);
+            return rc;
+        }
+        if (tl.empty()) {
+            pt::set_error("builtin scene `mesh`: mesh file has no triangles");
+            return PT_ERR_PARSE;
+        }
+        pt_object o;
+        memset(&o, 0, sizeof o);
+        o.kind = PT_MESH;
+        o.position[0] = -0.8f;
+        o.position[1] = -kBoxY + 0.5f;
+        o.position[2] = 0.0f;
+        o.color[0] = 234.0f / 255.0f;
+        o.color[1] = 1.0f;
+        o.color[2] = 0.0f;
+        o.reflect_type = PT_DIFFUSE;
+        o.tri_offset = 0;
+        o.tri_count = (uint32_t)tl.size();
+        pt::host::mesh_bounding_sphere(tl.data(), o.tri_count, o.bs_center, &o.bs_radius);
+        sc->triangles = tl;
+        sc->objects.push_back(o);
+        ObjDesc d;
+        d.variant = 1;
+        d.path = rel;
+        d.scale = scale;
+        sc->desc.push_back(d);
+        add_cornell_box(*sc);
+        sc->camera = builtin_camera(0.9f, -kBoxY + 1.8f, kBoxZ - 1.0f, -0.09f, -0.06f, -1.0f);
+    } else {
+        pt::set_error("unknown builtin scene `" + name + "`");
+        return PT_ERR_INVALID;
+    }
+    *out = sc.release();
+    return PT_OK;
+}
+
 // camera edits from a host (the GUI moves the camera, then saves: src/main.rs:245-251)
 int pt_scene_set_camera(pt_scene *s, const pt_camera *cam) {
     if (!s || !cam) {

@@ -52,3 +52,27 @@ def test_cli_errors(tmp_path):
     assert r.returncode == 1 and "cannot load scene" in r.stderr
     r = subprocess.run([CLI, "4", "16", "99", "--root", ptlib.ROOT], capture_output=True, text=True)
     assert r.returncode == 1 and "out of range" in r.stderr
+
+
+def test_cli_fills_an_empty_scenes_directory(tmp_path):
+    """load_scene_ids (scenes.rs:28-38): with no scenes/*.json the built-in scenes are written out first; the frame
+    rendered from the generated cornell.json is the frame of the shipped one."""
+    if not os.path.exists(CLI):
+        pytest.skip("CLI not built")
+    root = tmp_path / "root"
+    (root / "meshes").mkdir(parents=True)
+    os.symlink(os.path.join(ptlib.ROOT, "meshes", "mctri.off"), root / "meshes" / "mctri.off")
+    out = tmp_path / "out"
+    r = subprocess.run([CLI, "4", "16", "cornell", "--root", str(root), "--seed", "5", "--out", str(out)],
+                       cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert sorted(os.listdir(root / "scenes")) == sorted(s + ".json" for s in
+                                                         ["single-sphere", "cartesian", "two-spheres", "three-spheres",
+                                                          "cornell", "mesh"])
+    out2 = tmp_path / "out2"
+    r = subprocess.run([CLI, "4", "16", "cornell", "--root", ptlib.ROOT, "--seed", "5", "--out", str(out2)],
+                       cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    a = read_ppm(str(out / os.listdir(out)[0]))[3]
+    b = read_ppm(str(out2 / os.listdir(out2)[0]))[3]
+    assert (a == b).all()

@@ -213,3 +213,62 @@ def test_saved_bytes_equal_the_files_the_reference_wrote(sid, tmp_path):
     theirs = open(src).read().replace('    "updating_direction": null,\n', "")
     assert ours == theirs
     L.pt_scene_free(h)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# built-in scenes (setup_scenes, scenes.rs:43-318)
+L.pt_scene_builtin.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
+L.pt_builtin_scene_id.restype = C.c_char_p
+L.pt_builtin_scene_id.argtypes = [C.c_uint32]
+BUILTIN_ORDER = ["single-sphere", "cartesian", "two-spheres", "three-spheres", "cornell", "mesh"]
+
+
+def builtin(sid, base=None):
+    h = C.c_void_p()
+    rc = L.pt_scene_builtin(sid.encode(), (base or ptlib.ROOT).encode(), C.byref(h))
+    return rc, h
+
+
+def test_builtin_listing_is_the_reference_order():
+    assert [L.pt_builtin_scene_id(i).decode() for i in range(L.pt_builtin_scene_count())] == BUILTIN_ORDER
+    assert L.pt_builtin_scene_id(L.pt_builtin_scene_count()) is None
+
+
+@pytest.mark.parametrize("sid", BUILTIN_ORDER)
+def test_builtin_scene_equals_the_shipped_file(sid, tmp_path):
+    """The shipped scenes/*.json were written by SceneDescriptor::save from setup_scenes' values, so generating
+    a scene in code and saving it must give the bytes that loading the shipped file and saving it gives - objects,
+    quads, bounding spheres (Mesh::new's min + max*0.5 centre), the 12 bounding-box triangles and the camera.
+    Only mesh.json's camera was moved in the GUI before it was saved: there the built-in camera is checked against
+    CameraData::new((0.9, -0.2, 7.8), normalize(-0.09, -0.06, -1)) and the rest against the file."""
+    rc, h = builtin(sid)
+    assert rc == 0, L.pt_last_error()
+    rc, g = load_c(ptlib.scene_path(sid))
+    assert rc == 0, L.pt_last_error()
+    if sid == "mesh":
+        cam = L.pt_scene_camera(h).contents
+        f = np.float32
+        d = np.array([-0.09, -0.06, -1.0], f)
+        inv = f(1.0) / np.sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2], dtype=f)
+        assert list(cam.direction) == [float(x) for x in d * inv]
+        assert list(cam.position) == [float(f(0.9)), float(f(-2.0) + f(1.8)), float(f(8.8) - f(1.0))]
+        assert (cam.focal_length, cam.sensor_width, cam.aspect_ratio) == (float(f(0.035)), float(f(0.036)), 1.5)
+        assert L.pt_scene_set_camera(h, L.pt_scene_camera(g)) == 0
+    a, b = str(tmp_path / "builtin.json"), str(tmp_path / "loaded.json")
+    assert L.pt_scene_save(h, a.encode()) == 0 and L.pt_scene_save(g, b.encode()) == 0
+    assert open(a, "rb").read() == open(b, "rb").read()
+    n, m = C.c_uint32(), C.c_uint32()
+    n2, m2 = C.c_uint32(), C.c_uint32()
+    assert as_bytes(L.pt_scene_objects(h, C.byref(n)), n.value) == as_bytes(L.pt_scene_objects(g, C.byref(n2)), n2.value)
+    assert as_bytes(L.pt_scene_triangles(h, C.byref(m)), m.value) == as_bytes(L.pt_scene_triangles(g, C.byref(m2)), m2.value)
+    L.pt_scene_free(h)
+    L.pt_scene_free(g)
+
+
+def test_builtin_errors(tmp_path):
+    h = C.c_void_p()
+    assert L.pt_scene_builtin(b"no-such-scene", b".", C.byref(h)) == -1 and not h  # PT_ERR_INVALID
+    assert L.pt_scene_builtin(None, b".", C.byref(h)) == -1
+    # "mesh" needs meshes/mctri.off under base_dir (the reference panics in load_off, mod.rs:309)
+    assert L.pt_scene_builtin(b"mesh", str(tmp_path).encode(), C.byref(h)) < 0 and not h
+    assert b"mctri.off" in L.pt_last_error()
