@@ -181,6 +181,18 @@ __device__ __forceinline__ f32x2 ld2(const float (&p)[2]) {
     f32x2 r = {p[0], p[1]};
     return r;
 }
+// f_rcp of both halves: the native reciprocals are per half, the six refinement fmas run packed (v_pk_fma_f32);
+// every half goes through exactly f_rcp's sequence of IEEE operations, so the results are f_rcp's.
+__device__ __forceinline__ f32x2 f_rcp2(f32x2 d) {
+    const f32x2 one = splat2(1.0f);
+    const f32x2 r0 = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    const f32x2 e0 = __builtin_elementwise_fma(-d, r0, one);
+    const f32x2 r1 = __builtin_elementwise_fma(e0, r0, r0);
+    const f32x2 e1 = __builtin_elementwise_fma(-d, r1, one);
+    const f32x2 q1 = __builtin_elementwise_fma(e1, r1, r1);
+    const f32x2 e2 = __builtin_elementwise_fma(-d, q1, one);
+    return __builtin_elementwise_fma(e2, r1, q1);
+}
 
 // ---------------------------------------------------------------------------------------------
 // One ray against the two triangles of a TriPairRec: Triangle::intersect's arithmetic (mod.rs:559-594), both
@@ -195,7 +207,7 @@ __device__ __forceinline__ void test_pair(const TriPairRec &tr, f32x2 ox2, f32x2
     // pvec = ray.direction.cross(va_vc)                                       (mod.rs:563)
     const f32x2 px = dy2 * e2z - e2y * dz2, py = dz2 * e2x - e2z * dx2, pz = dx2 * e2y - e2x * dy2;
     const f32x2 determinant = (e1x * px + e1y * py) + e1z * pz;                // mod.rs:564
-    const f32x2 inv_det = {f_rcp(determinant[0]), f_rcp(determinant[1])};      // mod.rs:576
+    const f32x2 inv_det = f_rcp2(determinant);                                // mod.rs:576
     const f32x2 tx = ox2 - ld2(tr.ax), ty = oy2 - ld2(tr.ay), tz = oz2 - ld2(tr.az);  // mod.rs:577
     const f32x2 u = ((tx * px + ty * py) + tz * pz) * inv_det;                 // mod.rs:578
     // qvec = tvec.cross(va_vb)                                                (mod.rs:583)
