@@ -78,7 +78,7 @@ struct pt_ctx {
     DevBuf<unsigned long long> blk_rays, acc, total_rays;
     std::vector<hipEvent_t> ev_pool;
     // state of the frame being rendered (for pt_ctx_snapshot from the progress callback)
-    uint32_t live_npix = 0, live_spp_issued = 0;
+    uint32_t live_npix = 0, live_spp_issued = 0, live_streams = 1, live_m = 0;
     hipStream_t live_stream = nullptr;
     // concurrent pipelines (PT_FLAG_PIPELINES): child contexts that borrow this context's scene tables
     std::vector<pt_ctx *> pipes;
@@ -156,6 +156,7 @@ FrameParams make_frame(const pt_ctx *ctx, const pt_config *cfg, uint32_t idx_beg
     F.chunk_pixels = cfg->chunk_pixels;
     F.chunk_first = cfg->chunk_first;
     F.chunk_step = cfg->chunk_step;
+    F.n_streams = 1;  // set by the wavefront renderer
     F.seed_lo = (uint32_t)cfg->seed;
     F.seed_hi = (uint32_t)(cfg->seed >> 32);
     F.cam_px = ctx->cam.position[0];
@@ -197,8 +198,9 @@ double now_ms() {
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
-int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &F, hipStream_t st,
+int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, hipStream_t st,
                      const volatile uint8_t *cancel, pt_progress_fn cb, void *user, pt_stats *stats) {
+    FrameParams F = frame;
     const uint64_t npix = F.npix;
     uint64_t want = cfg->rays_per_pass ? cfg->rays_per_pass : (32u << 20);  // ~12 GB of queues: sized for 288 GB HBM
     uint32_t spp_pass = (uint32_t)(want / npix);
@@ -225,11 +227,14 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &F, hipS
     }
     int rc;
     if ((rc = c->hit.ensure(slots)) || (rc = c->cnt.ensure((size_t)kLevels * K)) || (rc = c->flags.ensure(1)) ||
-        (rc = c->blk_rays.ensure(K)) || (rc = c->acc.ensure(3 * npix)))
+        (rc = c->blk_rays.ensure(K)) || (rc = c->acc.ensure(3 * (size_t)K * m)))
         return rc;
     c->K = K;
     c->cap = cap;
-    HIP_TRY(hipMemsetAsync(c->acc.p, 0, 3 * npix * sizeof(unsigned long long), st));
+    F.n_streams = K;  // stream b owns pixels b, b+K, ...; accumulators are stream-major (K*m slots per channel)
+    c->live_streams = K;
+    c->live_m = m;
+    HIP_TRY(hipMemsetAsync(c->acc.p, 0, 3 * (size_t)K * m * sizeof(unsigned long long), st));
     HIP_TRY(hipMemsetAsync(c->blk_rays.p, 0, K * sizeof(unsigned long long), st));
     HIP_TRY(hipMemsetAsync(c->flags.p, 0, sizeof(uint32_t), st));
     HIP_TRY(hipMemsetAsync(c->cnt.p, 0, (size_t)kLevels * K * sizeof(uint32_t), st));
@@ -329,6 +334,8 @@ int render_mega(pt_ctx *c, const pt_config *cfg, const FrameParams &F, hipStream
     const uint64_t npix = F.npix;
     int rc;
     if ((rc = c->acc.ensure(3 * npix)) || (rc = c->total_rays.ensure(1))) return rc;
+    c->live_streams = 1;  // accumulators in pixel order
+    c->live_m = (uint32_t)npix;
     HIP_TRY(hipMemsetAsync(c->acc.p, 0, 3 * npix * sizeof(unsigned long long), st));
     HIP_TRY(hipMemsetAsync(c->total_rays.p, 0, sizeof(unsigned long long), st));
     if (cancel && *cancel) {
@@ -677,7 +684,7 @@ int pt_ctx_render(pt_ctx *c, const pt_config *cfg, void *d_out_rgb, void *hip_st
         rc = render_mega(c, cfg, F, st, cancel, cb, user, stats);
     if (rc == PT_OK || rc == PT_CANCELLED) {
         // a cancelled frame still resolves what was accumulated (the reference also writes the partial image)
-        launch_resolve(st, c->acc.p, (float *)d_out_rgb, F.npix, cfg->spp);
+        launch_resolve(st, c->acc.p, (float *)d_out_rgb, F.npix, cfg->spp, c->live_streams, c->live_m);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(st));
         if (cb && rc == PT_OK) cb(user, 1.0f);
@@ -753,7 +760,8 @@ int pt_ctx_snapshot(pt_ctx *c, void *d_out_rgb, uint32_t *spp_done) {
     }
     HIP_TRY(hipSetDevice(c->device));
     // stream order: the resolve runs after every pass issued so far, i.e. over live_spp_issued samples per pixel
-    launch_resolve(c->live_stream, c->acc.p, (float *)d_out_rgb, c->live_npix, c->live_spp_issued);
+    launch_resolve(c->live_stream, c->acc.p, (float *)d_out_rgb, c->live_npix, c->live_spp_issued, c->live_streams,
+                   c->live_m);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->live_stream));
     if (spp_done) *spp_done = c->live_spp_issued;

@@ -124,6 +124,7 @@ struct FrameParams {
     float sv_x, sv_y, sv_z;        // orthogonals().1
     uint32_t debug;                // ablation switches for profiling builds (PT_DEBUG env): 0 in production
     uint32_t chunk_pixels, chunk_first, chunk_step;  // interleaved partition (chunk_step <= 1: contiguous band)
+    uint32_t n_streams;            // wavefront: K ray streams; stream b owns the call's pixels b, b+K, b+2K, ...
 };
 
 // framebuffer index of the k-th pixel of this call (identity + idx_begin for a contiguous band)
@@ -141,7 +142,19 @@ struct ShadeParams {
     uint32_t debug;
     uint32_t s0;  // first sample index of the pass
     uint32_t chunk_pixels, chunk_first, chunk_step;
+    uint32_t n_streams;
 };
+
+// Pixels of a call are dealt to the K streams round-robin: stream b owns the call-local pixels b, b+K, b+2K, ...
+// (its j-th pixel is j*K + b).  Every stream then samples the whole band instead of one short run of a row, so the
+// streams of a launch carry nearly the same number of rays whatever the picture shows and however small the band
+// of this rank is (a stream of consecutive pixels that lies on the glass sphere carries 3-4x the rays of one on a
+// wall, and a launch ends with its slowest stream).  Accumulators are kept stream-major (slot b*m + j) so that a
+// stream's flush stays one contiguous run; k_resolve undoes the permutation.
+PT_HD uint32_t stream_pixel(uint32_t n_streams, uint32_t b, uint32_t j) { return j * n_streams + b; }
+PT_HD uint32_t stream_pixel_count(uint32_t npix, uint32_t n_streams, uint32_t b) {
+    return b < npix ? (npix - b + n_streams - 1u) / n_streams : 0u;
+}
 
 // Per-ray bookkeeping word as stored in a stream (4 B, the w lane of the throughput packet): a stream owns at
 // most 1024 pixels and a pass holds at most 32767 samples of a pixel, so both are stored relative to the stream /

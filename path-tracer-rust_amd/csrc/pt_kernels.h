@@ -28,7 +28,9 @@ void launch_shade(hipStream_t st, uint32_t K, const DevScene &S, const FramePara
                   unsigned long long *acc, uint32_t *flags, uint32_t m, uint32_t s0);
 void launch_scatter_chunks(hipStream_t st, const float *src, float *dst, uint32_t npix, uint32_t C, uint32_t n,
                            uint32_t j);
-void launch_resolve(hipStream_t st, const unsigned long long *acc, float *out, uint32_t npix, uint32_t spp);
+// acc is stream-major: pixel p = slot (p % n_streams) * m + p / n_streams of each colour plane (megakernel: 1, npix)
+void launch_resolve(hipStream_t st, const unsigned long long *acc, float *out, uint32_t npix, uint32_t spp,
+                    uint32_t n_streams, uint32_t m);
 void launch_mega(hipStream_t st, uint32_t grid, const DevScene &S, const FrameParams &F, unsigned long long *acc,
                  uint32_t chunk_spp, uint32_t n_chunks, unsigned long long *total_rays);
 void launch_query(hipStream_t st, const DevScene &S, const float *o, const float *d, uint32_t n, float *t,

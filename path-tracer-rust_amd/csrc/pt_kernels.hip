@@ -43,14 +43,13 @@ __device__ __forceinline__ void store_ray(const RayQueue &q, size_t at, vec3 o, 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_generate(FrameParams F, RayQueue q, uint32_t *__restrict__ cnt0,
                                                      uint32_t cap, uint32_t s0, uint32_t s_here, uint32_t m) {
-    // stream b = pixels [b*m, min((b+1)*m, npix)) x samples [s0, s0+s_here); lane order: pixel fastest
+    // stream b = its pixels (stream_pixel) x samples [s0, s0+s_here); lane order: pixel fastest
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
     const size_t base = (size_t)b * cap;
-    const uint32_t p0 = b * m;
-    const uint32_t mb = p0 < F.npix ? ((F.npix - p0) < m ? (F.npix - p0) : m) : 0u;
+    const uint32_t mb = stream_pixel_count(F.npix, F.n_streams, b);  // <= m
     const uint32_t n = mb * s_here;
     for (uint32_t g = tid; g < n; g += kBlock) {
-        const uint32_t pl = p0 + g % mb;
+        const uint32_t pl = stream_pixel(F.n_streams, b, g % mb);
         const uint32_t s = s0 + g / mb;
         const PathRay r = primary_ray(F, global_pixel(F, pl), s);
         store_ray(q, base + g, r.o, r.d, r.thr, pack_word(g % mb, g / mb, 0u, 1u));
@@ -106,7 +105,6 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, ShadeParams F, Ray
     for (uint32_t k = tid; k < 3u * m; k += kBlock) lds_acc[k] = 0ull;
     if (tid == 0) s_tail = 0;
     __syncthreads();
-    const uint32_t p0 = b * m;  // first pixel (band-local) of this stream
     const size_t base = (size_t)b * cap;
     bool overflow = false;
     // Software pipeline over the stream: the five loads of chunk j+1 are issued (unconditionally, whatever the
@@ -147,7 +145,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, ShadeParams F, Ray
                 in.d = mk(a.w, c.x, c.y);
                 in.thr = mk(tp.x, tp.y, tp.z);
                 word = __float_as_uint(tp.w);
-                in.pix = global_pixel(F, p0 + word_pix(word));
+                in.pix = global_pixel(F, stream_pixel(F.n_streams, b, word_pix(word)));
                 in.meta = pack_meta(F.s0 + word_sample(word), word_depth(word), word_branch(word));
                 shade_hit(S, F, in, h, so);
                 if (so.emits && !(F.debug & 1u)) add_radiance_lds(lds_acc, m, word_pix(word), so.contrib);
@@ -182,23 +180,28 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, ShadeParams F, Ray
     __syncthreads();
     if (tid == 0) cnt_out[b] = s_tail < cap ? s_tail : cap;
     // flush: this workgroup is the only writer of its pixels, launches on the stream are ordered
-    const uint32_t mb = (F.npix - p0) < m ? (F.npix - p0) : m;
+    const uint32_t mb = stream_pixel_count(F.npix, F.n_streams, b);
+    const size_t plane = (size_t)F.n_streams * m;  // accumulator slots per colour channel (stream-major)
     for (uint32_t k = tid; k < 3u * mb; k += kBlock) {
         const uint32_t c = k / mb, p = k - c * mb;
         const unsigned long long v = lds_acc[c * m + p];
-        if (v) acc[(size_t)c * F.npix + p0 + p] += v;
+        if (v) acc[(size_t)c * plane + (size_t)b * m + p] += v;
     }
 #undef s_tail
 }
 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_resolve(const unsigned long long *__restrict__ acc,
-                                                    float *__restrict__ out, uint32_t npix, uint32_t spp) {
+                                                    float *__restrict__ out, uint32_t npix, uint32_t spp,
+                                                    uint32_t n_streams, uint32_t m) {
     const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= npix) return;
+    // pixel p is pixel j = p / K of stream b = p % K; its accumulator is slot b*m + j (megakernel: K = 1, m = npix)
+    const size_t plane = (size_t)n_streams * m;
+    const size_t slot = (size_t)(p % n_streams) * m + p / n_streams;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const double sum = (double)acc[(size_t)c * npix + p] * (1.0 / 4294967296.0);
+        const double sum = (double)acc[(size_t)c * plane + slot] * (1.0 / 4294967296.0);
         const float v = (float)sum / (float)spp;  // radiance_v / samples_per_pixel, mod.rs:849
         out[(size_t)p * 3 + c] = clamp01(v);      // mod.rs:852-856
     }
@@ -388,6 +391,7 @@ void launch_shade(hipStream_t st, uint32_t K, const DevScene &S, const FramePara
     ShadeParams P;
     P.idx_begin = F.idx_begin;
     P.npix = F.npix;
+    P.n_streams = F.n_streams;
     P.seed_lo = F.seed_lo;
     P.seed_hi = F.seed_hi;
     P.debug = F.debug;
@@ -402,8 +406,10 @@ void launch_scatter_chunks(hipStream_t st, const float *src, float *dst, uint32_
                            uint32_t j) {
     hipLaunchKernelGGL(k_scatter_chunks, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, st, src, dst, npix, C, n, j);
 }
-void launch_resolve(hipStream_t st, const unsigned long long *acc, float *out, uint32_t npix, uint32_t spp) {
-    hipLaunchKernelGGL(k_resolve, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, st, acc, out, npix, spp);
+void launch_resolve(hipStream_t st, const unsigned long long *acc, float *out, uint32_t npix, uint32_t spp,
+                    uint32_t n_streams, uint32_t m) {
+    hipLaunchKernelGGL(k_resolve, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, st, acc, out, npix, spp,
+                       n_streams, m);
 }
 void launch_mega(hipStream_t st, uint32_t grid, const DevScene &S, const FrameParams &F, unsigned long long *acc,
                  uint32_t chunk_spp, uint32_t n_chunks, unsigned long long *total_rays) {
