@@ -207,9 +207,18 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
     if (spp_pass == 0) spp_pass = 1;
     if (spp_pass > cfg->spp) spp_pass = cfg->spp;
     if (spp_pass > kMaxPassSpp) spp_pass = kMaxPassSpp;  // sample-in-pass field of the stream bookkeeping word
-    // stream b owns m consecutive pixels of the band (all samples of a pass): about 2048 streams, at most
-    // kMaxStreamPixels pixels each (their radiance accumulators live in LDS inside k_shade)
-    uint32_t m = (uint32_t)((npix + 2047) / 2048);
+    // Streams: many more than the 2048 workgroups the chip holds at once, so that the dispatcher keeps every CU busy
+    // until a launch ends, but each still a few launches' worth of work for its workgroup - about 2048 primary rays
+    // per stream and pass (measured on cornell 1024x768: 2048 streams 22.0, 8192 24.3, 16384 24.7, 65536 23.2 G
+    // bounces/s).  A stream owns at most kMaxStreamPixels pixels (their accumulators live in LDS inside k_shade).
+    // (scenes with a BVH stage its nodes into LDS once per workgroup: twice the work per stream; mesh.json 2048 streams
+    // 7.3, 8192 7.6, 16384 7.0)
+    const uint64_t per_stream = c->scene.n_bvh_nodes != 0u ? 4096u : 2048u;
+    uint64_t k_target = ((uint64_t)npix * spp_pass + per_stream - 1u) / per_stream;
+    if (k_target < 2048u) k_target = 2048u;
+    if (const char *e = getenv("PT_STREAMS")) k_target = (uint64_t)atoll(e) > 0 ? (uint64_t)atoll(e) : k_target;  // tuning
+    uint32_t m = (uint32_t)((npix + k_target - 1) / k_target);
+    if (m == 0) m = 1;
     if (m > kMaxStreamPixels) m = kMaxStreamPixels;
     const uint32_t K = (uint32_t)((npix + m - 1) / m);
     // a primary ray has at most 4 descendants alive at one depth (two refract splits, mod.rs:760)
