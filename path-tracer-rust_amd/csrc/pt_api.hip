@@ -250,6 +250,9 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
 
     const uint32_t n_pass = (cfg->spp + spp_pass - 1) / spp_pass;
     const int n_depth = kMaxDepth;  // rays of depth 0..11 exist
+    // scenes without BVH meshes run a pass as one launch; PT_PASS_KERNEL=0 keeps the three-kernel form (A/B, profiling)
+    static const bool pass_kernel_off = getenv("PT_PASS_KERNEL") && atoi(getenv("PT_PASS_KERNEL")) == 0;
+    const bool one_kernel = c->scene.n_bvh_nodes == 0u && !pass_kernel_off;
     size_t ev_i = 0;
     hipEvent_t ev_begin = get_event(c, ev_i++), ev_end = get_event(c, ev_i++);
     hipEvent_t pass_done[2] = {get_event(c, ev_i++), get_event(c, ev_i++)};
@@ -271,8 +274,28 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
         if (cb && p >= 2) cb(user, (float)(p - 1) / (float)n_pass);
         const uint32_t s0 = p * spp_pass;
         const uint32_t s_here = (cfg->spp - s0) < spp_pass ? (cfg->spp - s0) : spp_pass;
-        launch_generate(st, K, F, queue_of(c, 0), c->cnt.p, cap, s0, s_here, m);
         c->live_spp_issued = s0 + s_here;
+        if (one_kernel) {  // the whole pass in one launch (k_pass)
+            hipEvent_t a = nullptr, b = nullptr;
+            if (c->profiling) {
+                a = get_event(c, ev_prof0 + 2 * n_prof), b = get_event(c, ev_prof0 + 2 * n_prof + 1);
+                if (!a || !b) {
+                    set_error("hipEventCreate failed");
+                    return PT_ERR_HIP;
+                }
+                HIP_TRY(hipEventRecord(a, st));
+            }
+            launch_pass(st, K, c->scene, F, queue_of(c, 0), queue_of(c, 1), cap, s0, s_here, m, c->acc.p, c->blk_rays.p,
+                        c->flags.p);
+            if (c->profiling) {
+                HIP_TRY(hipEventRecord(b, st));
+                ++n_prof;
+            }
+            HIP_TRY(hipEventRecord(pass_done[p & 1], st));
+            ++passes_done;
+            continue;
+        }
+        launch_generate(st, K, F, queue_of(c, 0), c->cnt.p, cap, s0, s_here, m);
         for (int d = 0; d < n_depth; ++d) {
             const RayQueue qin = queue_of(c, d & 1), qout = queue_of(c, (d + 1) & 1);
             if (c->profiling) {
@@ -306,7 +329,7 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
         for (auto v : rays) total += v;
         stats->ray_bounces = total;
         stats->intersect_rays = total;
-        stats->intersect_launches = passes_done * (uint32_t)n_depth;
+        stats->intersect_launches = one_kernel ? passes_done : passes_done * (uint32_t)n_depth;
         stats->passes = passes_done;
         uint64_t smp = 0;
         for (uint32_t p = 0; p < passes_done; ++p) {

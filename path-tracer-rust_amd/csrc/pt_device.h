@@ -190,6 +190,26 @@ __device__ __forceinline__ f32x2 splat2(float v) {
     f32x2 r = {v, v};
     return r;
 }
+// Load of a scene-table record whose index is the same for the whole wave.  The scene tables are written once by
+// pt_ctx_set_scene and never by a kernel, so the load goes through the constant address space: the backend then
+// always issues scalar loads (s_load_dwordx16/x4 into SGPRs), whatever it can or cannot prove about the kernel's own
+// stores.  With a plain global load it falls back to per-lane loads of the same address as soon as a store through
+// a pointer it cannot tell apart appears in the kernel (k_pass appends rays): 2x slower, the packed pair tests want
+// their operands in SGPR pairs.
+template <class T>
+__device__ __forceinline__ T ld_uniform(const T *p) {
+    static_assert(sizeof(T) % 16 == 0 && alignof(T) >= 16, "records are whole 16-byte rows");
+    typedef uint32_t row_t __attribute__((ext_vector_type(4)));
+    union {
+        T v;
+        row_t w[sizeof(T) / 16];
+    } u;
+    const __attribute__((address_space(4))) row_t *q =
+        (const __attribute__((address_space(4))) row_t *)(unsigned long long)p;
+#pragma unroll
+    for (uint32_t i = 0; i < sizeof(T) / 16; ++i) u.w[i] = q[i];
+    return u.v;
+}
 __device__ __forceinline__ f32x2 ld2(const float (&p)[2]) {
     f32x2 r = {p[0], p[1]};
     return r;
@@ -407,9 +427,9 @@ __device__ __forceinline__ void consider_object(const DevScene &S, const ObjPair
         const uint32_t pb = ob.pair_begin[hf], pc = ob.pair_count[hf];
         if (root == kNoBvh) {
             for (uint32_t p = 0; p < pc; ++p)  // wave-uniform index -> scalar loads
-                test_pair<true>(S.tri_pairs[pb + p], ox2, oy2, oz2, dx2, dy2, dz2, mt, mid);
+                test_pair<true>(ld_uniform(S.tri_pairs + (pb + p)), ox2, oy2, oz2, dx2, dy2, dz2, mt, mid);
         } else {  // BVH switched off for this frame: the reference's full scan over BVH-ordered records
-            for (uint32_t p = 0; p < pc; ++p) test_pair<false>(S.tri_pairs[pb + p], ox2, oy2, oz2, dx2, dy2, dz2, mt, mid);
+            for (uint32_t p = 0; p < pc; ++p) test_pair<false>(ld_uniform(S.tri_pairs + (pb + p)), ox2, oy2, oz2, dx2, dy2, dz2, mt, mid);
         }
     }
     if (sph_hit && mid >= 0 && mt < best_t) {
@@ -431,7 +451,7 @@ __device__ __forceinline__ HitRec scan_scene(const DevScene &S, vec3 o, vec3 d, 
     const f32x2 dx2 = splat2(d.x), dy2 = splat2(d.y), dz2 = splat2(d.z);
     const uint32_t n_pairs = (S.n_objs + 1u) >> 1;
     for (uint32_t p = 0; p < n_pairs; ++p) {
-        const ObjPairRec ob = S.obj_pairs[p];  // wave-uniform -> scalar loads
+        const ObjPairRec ob = ld_uniform(S.obj_pairs + p);  // wave-uniform -> scalar loads
         // intersect_sphere's discriminant (mod.rs:413-416) for both objects of the pair
         const f32x2 opx = ld2(ob.cx) - ox2, opy = ld2(ob.cy) - oy2, opz = ld2(ob.cz) - oz2;
         const f32x2 b = (opx * dx2 + opy * dy2) + opz * dz2;

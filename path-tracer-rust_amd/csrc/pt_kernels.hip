@@ -191,6 +191,121 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, ShadeParams F, Ray
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_pass: one launch renders one whole pass.  Streams never exchange rays - workgroup b reads level d of stream b
+// and appends to level d+1 of stream b - so nothing in a pass needs a grid-wide barrier: workgroup b generates the
+// primary rays of its pixels in registers, finds their hits, shades them, appends the survivors to its slice of the
+// queue, and then walks that slice level by level (workgroup barriers only) until the stream is empty.  Against the
+// three-kernel form this removes 25 launches (and 24 drains of the whole chip) per pass, the hit records and the
+// second read of every ray (intersect and shade of a ray happen back to back, 40 B in + 40 B out per bounce), the
+// write and re-read of the primary rays, and it lets streams that are intersecting (VALU-bound) share a CU with
+// streams that are waiting on their queue loads.  The accumulators stay in LDS for the whole pass and are flushed
+// once.  Scenes with a BVH keep the three-kernel form (their intersect step wants 512-thread workgroups).
+__global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, RayQueue q0, RayQueue q1, uint32_t cap,
+                                                 uint32_t s0, uint32_t s_here, uint32_t m,
+                                                 unsigned long long *__restrict__ acc,
+                                                 unsigned long long *__restrict__ blk_rays,
+                                                 uint32_t *__restrict__ flags) {
+    unsigned long long *lds_acc = reinterpret_cast<unsigned long long *>(dyn_lds);
+    uint32_t *s_tail_p = reinterpret_cast<uint32_t *>(lds_acc + 3u * m);
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t mb = stream_pixel_count(F.npix, F.n_streams, b);  // <= m
+    if (mb == 0u) return;
+    for (uint32_t k = tid; k < 3u * m; k += kBlock) lds_acc[k] = 0ull;
+    if (tid == 0) s_tail_p[0] = s_tail_p[1] = 0u;  // appends of level d are counted in s_tail_p[d & 1]
+    const size_t base = (size_t)b * cap;
+    ShadeParams P;
+    P.idx_begin = F.idx_begin;
+    P.npix = F.npix;
+    P.n_streams = F.n_streams;
+    P.seed_lo = F.seed_lo;
+    P.seed_hi = F.seed_hi;
+    P.debug = F.debug;
+    P.s0 = s0;
+    P.chunk_pixels = F.chunk_pixels;
+    P.chunk_first = F.chunk_first;
+    P.chunk_step = F.chunk_step;
+    bool overflow = false;
+    unsigned long long total = 0ull;
+    uint32_t n = mb * s_here;  // rays of the current level
+    for (uint32_t depth = 0; depth < (uint32_t)kMaxDepth && n != 0u; ++depth) {
+        const RayQueue qin = (depth & 1u) ? q1 : q0, qout = (depth & 1u) ? q0 : q1;  // level 0 is never stored
+        __syncthreads();  // level `depth` of the stream is complete and visible to the whole workgroup
+        // the other counter was last read before this barrier (end of the level before) and is next added to after
+        // the next one
+        if (tid == 0) s_tail_p[(depth + 1u) & 1u] = 0u;
+        uint32_t *const tail_p = s_tail_p + (depth & 1u);
+        total += n;
+        for (uint32_t j0 = 0; j0 < n; j0 += kBlock) {  // uniform trip count: every lane reaches the ballots
+            const uint32_t i = j0 + tid;
+            PathRay in;
+            uint32_t word = 0;
+            if (i < n) {
+                if (depth == 0u) {  // render_pixel's ray for (pixel i % mb of the stream, sample s0 + i / mb)
+                    const uint32_t pj = i % mb, sj = i / mb;
+                    in = primary_ray(F, global_pixel(F, stream_pixel(F.n_streams, b, pj)), s0 + sj);
+                    word = pack_word(pj, sj, 0u, 1u);
+                } else {
+                    const float4 a = qin.od0[base + i], tp = qin.tp[base + i];
+                    const float2 c = qin.od1[base + i];
+                    in.o = mk(a.x, a.y, a.z);
+                    in.d = mk(a.w, c.x, c.y);
+                    in.thr = mk(tp.x, tp.y, tp.z);
+                    word = __float_as_uint(tp.w);
+                }
+            }
+            ShadeOut so;
+            so.n_rays = 0;
+            so.emits = false;
+            if (i < n) {
+                const HitRec h = intersect_scene_dev<false>(S, in.o, in.d, nullptr);
+                if (h.id >= 0) {
+                    in.pix = global_pixel(F, stream_pixel(F.n_streams, b, word_pix(word)));
+                    in.meta = pack_meta(s0 + word_sample(word), word_depth(word), word_branch(word));
+                    shade_hit(S, P, in, h, so);
+                    if (so.emits) add_radiance_lds(lds_acc, m, word_pix(word), so.contrib);
+                }
+            }
+            // stream compaction: survivors first (path order kept inside the wave), split children after them
+            const uint64_t m1 = __builtin_amdgcn_ballot_w64(so.n_rays >= 1);
+            const uint64_t m2 = __builtin_amdgcn_ballot_w64(so.n_rays == 2);
+            const uint32_t c1 = (uint32_t)__builtin_popcountll(m1), c2 = (uint32_t)__builtin_popcountll(m2);
+            uint32_t wbase = 0;
+            if ((tid & 63u) == 0u && (c1 + c2) != 0u) wbase = atomicAdd(tail_p, c1 + c2);
+            wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+            if (so.n_rays >= 1) {
+                const uint32_t slot = wbase + lane_prefix(m1);
+                if (slot < cap)
+                    store_ray(qout, base + slot, so.x, so.d0, so.thr0,
+                              pack_word(word_pix(word), word_sample(word), meta_depth(so.meta0), meta_branch(so.meta0)));
+                else
+                    overflow = true;
+            }
+            if (so.n_rays == 2) {
+                const uint32_t slot = wbase + c1 + lane_prefix(m2);
+                if (slot < cap)
+                    store_ray(qout, base + slot, so.x, so.d1, so.thr1,
+                              pack_word(word_pix(word), word_sample(word), meta_depth(so.meta1), meta_branch(so.meta1)));
+                else
+                    overflow = true;
+            }
+        }
+        __syncthreads();  // every append of this level is counted
+        const uint32_t tail = *tail_p;
+        n = tail < cap ? tail : cap;
+    }
+    if (overflow) atomicOr(flags, 1u);
+    __syncthreads();
+    if (tid == 0) blk_rays[b] += total;
+    // flush once per pass: this workgroup is the only writer of its pixels, launches on the stream are ordered
+    const size_t plane = (size_t)F.n_streams * m;
+    for (uint32_t k = tid; k < 3u * mb; k += kBlock) {
+        const uint32_t c = k / mb, p = k - c * mb;
+        const unsigned long long v = lds_acc[c * m + p];
+        if (v) acc[(size_t)c * plane + (size_t)b * m + p] += v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_resolve(const unsigned long long *__restrict__ acc,
                                                     float *__restrict__ out, uint32_t npix, uint32_t spp,
                                                     uint32_t n_streams, uint32_t m) {
@@ -401,6 +516,12 @@ void launch_shade(hipStream_t st, uint32_t K, const DevScene &S, const FramePara
     P.chunk_step = F.chunk_step;
     hipLaunchKernelGGL(k_shade, dim3(K), dim3(kBlock), lds, st, S, P, qin, qout, hit, cnt_in, cnt_out, cap, acc,
                        flags, m);
+}
+void launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const FrameParams &F, const RayQueue &q0,
+                 const RayQueue &q1, uint32_t cap, uint32_t s0, uint32_t s_here, uint32_t m, unsigned long long *acc,
+                 unsigned long long *blk_rays, uint32_t *flags) {
+    const size_t lds = (size_t)3 * m * sizeof(unsigned long long) + 16;
+    hipLaunchKernelGGL(k_pass, dim3(K), dim3(kBlock), lds, st, S, F, q0, q1, cap, s0, s_here, m, acc, blk_rays, flags);
 }
 void launch_scatter_chunks(hipStream_t st, const float *src, float *dst, uint32_t npix, uint32_t C, uint32_t n,
                            uint32_t j) {
