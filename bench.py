@@ -3,17 +3,20 @@
 
 One step = one whole frame of BASELINE.json's metric workload (scenes/cornell.json, 1024x768, 4096 spp by
 default) rendered by the wavefront HIP pipeline through the C ABI, the scene already resident in HBM.
-With N ranks (one process per GPU, launched by torch.distributed.run) the frame is cut into N contiguous
-bands of framebuffer indices, every rank renders its band, and one RCCL all-gather assembles the image:
-total work is fixed, so scaling is "strong".  value = ray bounces of all ranks / max-over-ranks time.
+With N ranks (one process per GPU, launched by torch.distributed.run) rank r renders image rows r, r+N, ...,
+and one RCCL all-gather assembles the image: total work is fixed, so scaling is "strong".
+value = ray bounces of all ranks / max-over-ranks time.
 
 The JSON line also carries
-  roofline      the intersect kernel: algorithmic 32 B per ray (24 B ray in + 8 B hit out) times the rays its
-                launches processed, divided by the HIP-event time of those launches measured live in the
-                timed region, against the 8 TB/s HBM peak;
+  roofline      the dominant kernel, timed live with HIP events around each of its launches in the timed region,
+                against the 8 TB/s HBM peak.  Scenes without BVH meshes (the default) run a whole pass per launch
+                (k_pass): its algorithmic traffic is the ray queue - every ray of depth >= 1 is written once and
+                read once, 40 B each way (origin, direction, throughput, bookkeeping word); primary rays are made in
+                registers and hit records never leave them.  Scenes with a BVH run generate / intersect / shade as
+                separate kernels and the figure is k_intersect's (24 B ray in + 8 B hit out per ray);
   cpu_baseline  the oracle (CPU port of the reference's rayon loop; the Rust reference cannot be built in
                 this image) timed on this box's host cores on a bounded sample of the same workload;
-  variants      the persistent megakernel backend on the same frame.
+  variants      the persistent megakernel backend and two concurrent pipelines on the same frame.
 """
 import argparse
 import importlib
@@ -26,7 +29,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-INTERSECT_BYTES_PER_RAY = 32  # 24 B (o, d) read + 8 B (t, id) written
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4  # 256 CUs x 4 SIMDs, one wave instruction per 4 cycles at 2.4 GHz
+INTERSECT_BYTES_PER_RAY = 32  # k_intersect: 24 B (o, d) read + 8 B (t, id) written
+QUEUE_BYTES_PER_STORED_RAY = 80  # k_pass: a ray of depth >= 1 is appended (40 B) and read back (40 B) exactly once
 
 
 def host_cpu_share(limit):
@@ -155,7 +160,7 @@ def main():
             step(backend, profile, pipelines)
         barrier()
         t0 = time.perf_counter()
-        bounces = isect_rays = 0
+        bounces = isect_rays = samples = passes = 0
         isect_ms = 0.0
         launches = 0
         for _ in range(steps):
@@ -164,6 +169,8 @@ def main():
             isect_rays += st.intersect_rays
             isect_ms += st.ms_intersect
             launches += st.intersect_launches
+            samples += st.samples
+            passes += st.passes
         barrier()
         dt = time.perf_counter() - t0
         if dist is not None:
@@ -173,7 +180,8 @@ def main():
             b = torch.tensor([bounces], dtype=torch.int64, device=coll_dev)
             dist.all_reduce(b, op=dist.ReduceOp.SUM)
             bounces = int(b.item())
-        return dict(dt=dt, bounces=bounces, isect_rays=isect_rays, isect_ms=isect_ms, launches=launches, image=full)
+        return dict(dt=dt, bounces=bounces, isect_rays=isect_rays, isect_ms=isect_ms, launches=launches, image=full,
+                    samples=samples, passes=passes)
 
     main_run = timed(args.backend, args.steps, args.warmup, profile=(args.backend == "wavefront" and args.pipelines == 1),
                      pipelines=args.pipelines)
@@ -204,24 +212,36 @@ def main():
         },
     }
     if args.backend == "wavefront" and main_run["isect_ms"] > 0:
-        # rank 0's intersect launches (every rank runs the same kernel on its own band)
-        achieved = INTERSECT_BYTES_PER_RAY * main_run["isect_rays"] / (main_run["isect_ms"] * 1e-3) / 1e9
+        # rank 0's launches of the dominant kernel (every rank runs the same kernel on its own rows)
+        one_kernel = main_run["launches"] == main_run["passes"]  # one launch per pass: k_pass
+        rays, ms, launches = main_run["isect_rays"], main_run["isect_ms"], max(1, main_run["launches"])
+        if one_kernel:
+            kernel = "k_pass"
+            stored = rays - main_run["samples"]  # rays of depth >= 1
+            alg_bytes = QUEUE_BYTES_PER_STORED_RAY * stored
+            per_unit = {"bytes_per_stored_ray": QUEUE_BYTES_PER_STORED_RAY, "stored_rays_per_launch": stored / launches,
+                        "bytes_per_ray_bounce": alg_bytes / rays}
+        else:
+            kernel = "k_intersect"
+            alg_bytes = INTERSECT_BYTES_PER_RAY * rays
+            per_unit = {"bytes_per_ray": INTERSECT_BYTES_PER_RAY}
+        achieved = alg_bytes / (ms * 1e-3) / 1e9
         out["roofline"] = {
-            "kernel": "k_intersect",
+            "kernel": kernel,
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": None,
-            "algorithmic_bytes_per_launch": INTERSECT_BYTES_PER_RAY * main_run["isect_rays"] / max(1, main_run["launches"]),
-            "bytes_per_ray": INTERSECT_BYTES_PER_RAY,
-            "rays_per_launch": main_run["isect_rays"] / max(1, main_run["launches"]),
-            "avg_launch_ms": main_run["isect_ms"] / max(1, main_run["launches"]),
-            "intersect_rays_per_s": main_run["isect_rays"] / (main_run["isect_ms"] * 1e-3),
-            "launches": main_run["launches"],
+            "algorithmic_bytes_per_launch": alg_bytes / launches,
+            "rays_per_launch": rays / launches,
+            "avg_launch_ms": ms / launches,
+            "rays_per_s": rays / (ms * 1e-3),
+            "launches": launches,
         }
-        prof = os.path.join(ROOT, "profiles", "r01_intersect_traffic.json")
+        out["roofline"].update(per_unit)
+        prof = os.path.join(ROOT, "profiles", "r01_%s_traffic.json" % kernel)
         if os.path.exists(prof):
             try:
                 with open(prof) as f:
@@ -232,10 +252,12 @@ def main():
                 out["roofline"]["traffic_bytes_per_ray"] = tr["hbm_bytes_per_ray"]
                 out["roofline"]["traffic_source"] = tr.get("source")
                 if "valu" in tr:  # the resource that actually binds this kernel (from the same committed profile)
+                    wave_insts = tr["valu"]["insts_per_ray"] * out["roofline"]["rays_per_s"] / 64.0
                     out["roofline"]["binding_resource"] = {
                         "name": "VALU instruction issue", "valu_insts_per_ray": tr["valu"]["insts_per_ray"],
-                        "valu_busy_frac": tr["valu"]["busy_frac"],
-                        "valu_wave_insts_per_s": tr["valu"]["insts_per_ray"] * out["roofline"]["intersect_rays_per_s"] / 64.0}
+                        "valu_busy_frac": tr["valu"]["busy_frac"], "valu_wave_insts_per_s": wave_insts,
+                        "valu_issue_peak_wave_insts_per_s": VALU_ISSUE_PEAK,
+                        "frac_of_valu_issue_peak": wave_insts / VALU_ISSUE_PEAK}
             except Exception:
                 pass
     if rank == 0 and world == 1 and not args.no_variants:

@@ -1,27 +1,31 @@
 // pt_kernels.hip — gfx950 kernels of the wavefront radiance() pipeline and the persistent megakernel.
 //
-// Wavefront pipeline (one pass = P primary rays):
-//   k_generate                         tent filter + pinhole ray        (render_pixel, mod.rs:812-843)
-//   for depth = 0..11:
-//     k_intersect                      closest hit per ray              (intersect_scene, mod.rs:631-659)
-//     k_shade                          roulette, emission, BRDF sample, (radiance body, mod.rs:665-789)
-//                                      refract split, stream compaction
+// Wavefront pipeline (one pass = P primary rays), scenes without BVH meshes:
+//   k_pass                             the whole pass in one launch: per workgroup (= ray stream) the primary rays
+//                                      (render_pixel, mod.rs:812-843), then level by level closest hit
+//                                      (intersect_scene, mod.rs:631-659), roulette / emission / BRDF sample / refract
+//                                      split (radiance body, mod.rs:665-789) and stream compaction
+// scenes with a BVH (and PT_PASS_KERNEL=0): the same steps as separate kernels
+//   k_generate; for depth = 0..11: k_intersect, k_shade
 //   k_resolve (once per frame)         /spp, clamp                      (mod.rs:849-856)
 //
-// Ray streams.  The ray queue is cut into K block-private streams: workgroup b of every kernel reads
-// stream b of the current level and appends survivors to stream b of the next level.  A stream is a
-// contiguous slice [b*cap, b*cap+count[b]) of each queue array, so
+// Ray streams.  The ray queue is cut into K workgroup-private streams: workgroup b reads stream b of the current
+// level and appends survivors to stream b of the next level.  A stream is a contiguous slice
+// [b*cap, b*cap+count) of each queue array, so
 //   * loads/stores are fully coalesced 16-/8-/4-byte per lane accesses,
 //   * compaction needs no global atomic at all: wave ballot + mbcnt prefix gives the slot inside the
 //     wave, one LDS add per wave orders the waves of the workgroup, and the stream length is a plain
 //     store at the end (a single global tail counter would saturate at ~90 M atomics/s on this chip),
-//   * stream b owns the pixels [b*m, (b+1)*m) of the band (all samples of the pass): every contribution to
-//     those pixels is produced by workgroup b, so radiance is summed with LDS atomics inside a launch and
-//     flushed to the frame accumulator by plain read-modify-write stores - no global atomic in the pipeline
-//     (global 64-bit atomics cost 27 % of k_shade when they were used: profiles/README.md),
-//   * K >> 256 CUs workgroups keep every XCD busy and the hardware dispatcher balances streams of unequal decay.
+//   * stream b owns the pixels b, b+K, b+2K, ... of the call (all samples of the pass): every contribution to
+//     those pixels is produced by workgroup b, so radiance is summed with LDS atomics and flushed to the frame
+//     accumulator by plain read-modify-write stores - no global atomic in the pipeline (global 64-bit atomics cost
+//     27 % of k_shade when they were used: profiles/README.md) - and every stream samples the whole picture, so
+//     the streams of a launch carry the same load,
+//   * no ray ever crosses streams, so a pass needs no grid-wide barrier: k_pass,
+//   * K (16 K on the bench frame) >> the 1536-2048 workgroups the chip holds: the dispatcher keeps every CU busy.
 // Queue arrays (per ray): od0 = (ox,oy,oz,dx) 16 B, od1 = (dy,dz) 8 B, tp = (throughput rgb, bookkeeping word) 16 B;
-// hit = (t, id) 8 B.  intersect moves 24+8 = 32 B/ray, shade 48 B in + 40 B out per survivor.
+// hit = (t, id) 8 B (three-kernel form only).  k_pass moves 40 B out + 40 B in per ray of depth >= 1; the separate
+// kernels 32 B/ray (intersect) and 48 B in + 40 B out per survivor (shade).
 #include "pt_kernels.h"
 
 namespace pt {

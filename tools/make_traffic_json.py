@@ -21,39 +21,37 @@ with open(os.path.join(ROOT, "profiles", name), "w") as f:
 
 
 def kernel(d, frag):
-    return next(v for k, v in d.items() if frag in k)
+    return next((v for k, v in d.items() if frag in k), None)
 
 
-ki = kernel(out["sq"], "k_intersect")
-fetch = kernel(out["fetch"], "k_intersect")["FETCH_SIZE"] * 1024.0  # counter is in KiB
-write = kernel(out["write"], "k_intersect")["WRITE_SIZE"] * 1024.0
-ks = kernel(out["sq"], "k_shade")
-fs = kernel(out["fetch"], "k_shade")["FETCH_SIZE"] * 1024.0
-ws = kernel(out["write"], "k_shade")["WRITE_SIZE"] * 1024.0
-tr = {
-    "kernel": "k_intersect",
-    "rays": rays,
-    "dispatches": ki["dispatches"],
-    "FETCH_SIZE_bytes": fetch,
-    "WRITE_SIZE_bytes": write,
-    "hbm_bytes_per_ray": (2.0 * fetch + write) / rays,
-    "correction": "FETCH_SIZE x2 (gfx950 tallies 128-B requests of wide coalesced reads at 64 B, MI355X_MICROARCH.md "
-                  "HBM section); WRITE_SIZE as reported; both in KiB",
-    "source": "profiles/%s: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 1 "
-              "--warmup 0 %s`" % (name, bench_args),
-    "valu": {
-        "insts_per_ray": ki["SQ_INSTS_VALU"] * 64.0 / rays,
-        "busy_frac": ki["SQ_ACTIVE_INST_VALU"] / ki["SQ_BUSY_CYCLES"] / 8.0,
-        "note": "SQ_INSTS_VALU x 64 / rays; SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES / 8 (8 = all 32 SIMDs of a shader "
-                "engine issuing a VALU instruction every quad-cycle): the kernel is bound by VALU instruction issue, "
-                "not by HBM",
-    },
-    "k_shade": {
-        "insts_per_ray": ks["SQ_INSTS_VALU"] * 64.0 / rays,
-        "busy_frac": ks["SQ_ACTIVE_INST_VALU"] / ks["SQ_BUSY_CYCLES"] / 8.0,
-        "hbm_bytes_per_ray": (2.0 * fs + ws) / rays,
-    },
-}
-with open(os.path.join(ROOT, "profiles", "r01_intersect_traffic.json"), "w") as f:
-    json.dump(tr, f, indent=1)
-print(json.dumps(tr, indent=1))
+NOTE = ("SQ_INSTS_VALU x 64 / rays; SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES / 8 (8 = all 32 SIMDs of a shader engine issuing "
+        "a VALU instruction every quad-cycle): the kernel is bound by VALU instruction issue, not by HBM")
+done = {}
+for kname in ("k_pass", "k_intersect", "k_shade"):
+    sq = kernel(out["sq"], kname)
+    if sq is None:
+        continue
+    fetch = kernel(out["fetch"], kname)["FETCH_SIZE"] * 1024.0  # counter is in KiB
+    write = kernel(out["write"], kname)["WRITE_SIZE"] * 1024.0
+    tr = {
+        "kernel": kname,
+        "rays": rays,
+        "dispatches": sq["dispatches"],
+        "FETCH_SIZE_bytes": fetch,
+        "WRITE_SIZE_bytes": write,
+        "hbm_bytes_per_ray": (2.0 * fetch + write) / rays,
+        "correction": "FETCH_SIZE x2 (gfx950 tallies 128-B requests of wide coalesced reads at 64 B, "
+                      "MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported; both in KiB",
+        "source": "profiles/%s: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py "
+                  "--steps 1 --warmup 0 %s`" % (name, bench_args),
+        "valu": {
+            "insts_per_ray": sq["SQ_INSTS_VALU"] * 64.0 / rays,
+            "busy_frac": sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_BUSY_CYCLES"] / 8.0,
+            "note": NOTE,
+        },
+    }
+    done[kname] = tr
+    if kname != "k_shade":  # bench.py reads r01_<dominant kernel>_traffic.json
+        with open(os.path.join(ROOT, "profiles", "r01_%s_traffic.json" % kname), "w") as f:
+            json.dump(tr, f, indent=1)
+print(json.dumps(done, indent=1))
