@@ -116,12 +116,12 @@ typedef struct pt_config {
 typedef struct pt_stats {
     uint64_t ray_bounces;        /* number of intersect_scene evaluations (mod.rs:663), exact */
     uint64_t samples;            /* primary samples traced */
-    uint64_t intersect_rays;     /* rays processed by the intersect kernel (== ray_bounces for wavefront) */
-    uint32_t intersect_launches; /* launches of the intersect kernel */
+    uint64_t intersect_rays;     /* rays processed by the dominant kernel (== ray_bounces for wavefront) */
+    uint32_t intersect_launches; /* launches of the dominant kernel: k_pass (one per pass) or, for BVH scenes, k_intersect */
     uint32_t passes;
     double ms_total;     /* wall time of the call */
     double ms_device;    /* HIP-event time from first to last kernel of the call */
-    double ms_intersect; /* HIP-event time summed over intersect-kernel launches (only if PT profiling on) */
+    double ms_intersect; /* HIP-event time summed over those launches (only if PT profiling on) */
 } pt_stats;
 
 /* progress callback: fraction in [0,1]; invoked on the calling thread between passes */
@@ -162,7 +162,7 @@ int pt_device_malloc(int device, size_t bytes, void **out);
 int pt_device_free(int device, void *p);
 int pt_device_download(int device, void *dst_host, const void *src_device, size_t bytes);
 
-/* Enable HIP-event timing of every intersect-kernel launch (fills pt_stats.ms_intersect). */
+/* Enable HIP-event timing of every launch of the dominant kernel (fills pt_stats.ms_intersect). */
 int pt_ctx_set_profiling(pt_ctx *ctx, int enabled);
 
 /* Single-ray queries through the same device intersection code (a6): the callers are object
