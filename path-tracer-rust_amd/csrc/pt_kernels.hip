@@ -216,6 +216,10 @@ __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, R
     if (mb == 0u) return;
     for (uint32_t k = tid; k < 3u * m; k += kBlock) lds_acc[k] = 0ull;
     if (tid == 0) s_tail_p[0] = s_tail_p[1] = 0u;  // appends of level d are counted in s_tail_p[d & 1]
+    // framebuffer index (= RNG key) of each of the stream's pixels: the interleaved partition of a multi-GPU call
+    // makes it a division per lookup, and it is needed once per bounce
+    uint32_t *lds_pix = s_tail_p + 4;
+    for (uint32_t j = tid; j < mb; j += kBlock) lds_pix[j] = global_pixel(F, stream_pixel(F.n_streams, b, j));
     const size_t base = (size_t)b * cap;
     ShadeParams P;
     P.idx_begin = F.idx_begin;
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, R
             if (i < n) {
                 if (depth == 0u) {  // render_pixel's ray for (pixel i % mb of the stream, sample s0 + i / mb)
                     const uint32_t pj = i % mb, sj = i / mb;
-                    in = primary_ray(F, global_pixel(F, stream_pixel(F.n_streams, b, pj)), s0 + sj);
+                    in = primary_ray(F, lds_pix[pj], s0 + sj);
                     word = pack_word(pj, sj, 0u, 1u);
                 } else {
                     const float4 a = qin.od0[base + i], tp = qin.tp[base + i];
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, R
             if (i < n) {
                 const HitRec h = intersect_scene_dev<false>(S, in.o, in.d, nullptr);
                 if (h.id >= 0) {
-                    in.pix = global_pixel(F, stream_pixel(F.n_streams, b, word_pix(word)));
+                    in.pix = lds_pix[word_pix(word)];
                     in.meta = pack_meta(s0 + word_sample(word), word_depth(word), word_branch(word));
                     shade_hit(S, P, in, h, so);
                     if (so.emits) add_radiance_lds(lds_acc, m, word_pix(word), so.contrib);
@@ -524,7 +528,7 @@ void launch_shade(hipStream_t st, uint32_t K, const DevScene &S, const FramePara
 void launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const FrameParams &F, const RayQueue &q0,
                  const RayQueue &q1, uint32_t cap, uint32_t s0, uint32_t s_here, uint32_t m, unsigned long long *acc,
                  unsigned long long *blk_rays, uint32_t *flags) {
-    const size_t lds = (size_t)3 * m * sizeof(unsigned long long) + 16;
+    const size_t lds = (size_t)3 * m * sizeof(unsigned long long) + 16 + (size_t)m * sizeof(uint32_t);
     hipLaunchKernelGGL(k_pass, dim3(K), dim3(kBlock), lds, st, S, F, q0, q1, cap, s0, s_here, m, acc, blk_rays, flags);
 }
 void launch_scatter_chunks(hipStream_t st, const float *src, float *dst, uint32_t npix, uint32_t C, uint32_t n,
