@@ -51,6 +51,9 @@ extern "C" {
 
 /* pt_config.flags */
 #define PT_FLAG_NO_BVH 1u /* meshes are scanned triangle by triangle as the reference does (mod.rs:558) */
+/* Wavefront backend: generate / intersect / shade as separate kernels per depth even where a whole pass could run as
+ * one launch (scenes without BVH meshes).  Same image, bit for bit; for A/B checks and per-step profiling. */
+#define PT_FLAG_SEPARATE_KERNELS 2u
 /* Concurrent pipelines (wavefront backend): bits 8..11 of flags = n (2..8).  The call's pixels are dealt chunk by
  * chunk to n independent wavefront pipelines on n HIP streams of the same GPU, so the VALU-bound intersect kernels
  * of one pipeline overlap the HBM-bound shade kernels of another (cornell: +15 % with 2; 3 or more only help when

@@ -235,7 +235,9 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
             return rc;
     }
     int rc;
-    if ((rc = c->hit.ensure(slots)) || (rc = c->cnt.ensure((size_t)kLevels * K)) || (rc = c->flags.ensure(1)) ||
+    const bool needs_hits = c->scene.n_bvh_nodes != 0u || (cfg->flags & PT_FLAG_SEPARATE_KERNELS) ||
+                            (getenv("PT_PASS_KERNEL") && atoi(getenv("PT_PASS_KERNEL")) == 0);  // k_pass keeps hits in registers
+    if ((needs_hits && (rc = c->hit.ensure(slots))) || (rc = c->cnt.ensure((size_t)kLevels * K)) || (rc = c->flags.ensure(1)) ||
         (rc = c->blk_rays.ensure(K)) || (rc = c->acc.ensure(3 * (size_t)K * m)))
         return rc;
     c->K = K;
@@ -252,7 +254,7 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
     const int n_depth = kMaxDepth;  // rays of depth 0..11 exist
     // scenes without BVH meshes run a pass as one launch; PT_PASS_KERNEL=0 keeps the three-kernel form (A/B, profiling)
     static const bool pass_kernel_off = getenv("PT_PASS_KERNEL") && atoi(getenv("PT_PASS_KERNEL")) == 0;
-    const bool one_kernel = c->scene.n_bvh_nodes == 0u && !pass_kernel_off;
+    const bool one_kernel = c->scene.n_bvh_nodes == 0u && !pass_kernel_off && !(cfg->flags & PT_FLAG_SEPARATE_KERNELS);
     size_t ev_i = 0;
     hipEvent_t ev_begin = get_event(c, ev_i++), ev_end = get_event(c, ev_i++);
     hipEvent_t pass_done[2] = {get_event(c, ev_i++), get_event(c, ev_i++)};

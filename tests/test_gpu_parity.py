@@ -613,3 +613,45 @@ def test_concurrent_pipelines_same_image(gpu):
     # a band, 3 pipelines
     img, _ = render(PtConfig(w, h, spp, 0, 12, 130, 1500, 4000, 3 << 8))
     assert np.array_equal(img, whole[130:1500])
+
+
+PT_FLAG_SEPARATE_KERNELS = 2
+
+
+def _render_flags(gpu, sc, w, h, spp, seed, flags, rays_per_pass=0, chunks=None):
+    L, _ = gpu
+    cfg = PtConfig(w, h, spp, ptlib.BACKEND_WAVEFRONT, seed, 0, 0, rays_per_pass, flags)
+    if chunks:
+        cfg.chunk_pixels, cfg.chunk_first, cfg.chunk_step = chunks
+    out = np.zeros((w * h, 3), dtype=np.float32)  # pt_render puts the chunks of a share at their places in the frame
+    st = PtStats()
+    rc = L.pt_render(C.byref(cfg), C.byref(sc.cam), sc.objs, sc.n_objs, sc.tris, sc.n_tris, _np_f(out), None, None,
+                     None, C.byref(st))
+    assert rc == 0, L.pt_last_error()
+    return out, st
+
+
+@pytest.mark.parametrize("sid", ["cornell", "three-spheres", "cartesian", "single-sphere"])
+def test_pass_kernel_equals_separate_kernels(gpu, sid):
+    """k_pass (a whole pass per launch, the default for scenes without BVH meshes) and the generate / intersect /
+    shade kernels give the same image bits and the same bounce count: one pass, many ragged passes, an interleaved
+    share of the frame."""
+    sc = ptlib.load_scene_py(ptlib.scene_path(sid))
+    for (w, h, spp, rpp, chunks) in [(96, 64, 24, 0, None), (97, 53, 50, 97 * 53 * 7, None), (96, 64, 9, 0, (96, 1, 3)),
+                                     (33, 17, 3, 33 * 17, None)]:
+        a, sa = _render_flags(gpu, sc, w, h, spp, 11, 0, rpp, chunks)
+        b, sb = _render_flags(gpu, sc, w, h, spp, 11, PT_FLAG_SEPARATE_KERNELS, rpp, chunks)
+        assert sa.ray_bounces == sb.ray_bounces and sa.samples == sb.samples and sa.passes == sb.passes
+        assert sa.intersect_launches == sa.passes and sb.intersect_launches == 12 * sb.passes  # really two paths
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (sid, w, h, spp)
+
+
+def test_pass_kernel_full_size(gpu):
+    """Bench geometry (1024x768, 16 K streams): k_pass against the separate kernels and against the megakernel."""
+    sc = ptlib.load_scene_py(ptlib.scene_path("cornell"))
+    a, sa = _render_flags(gpu, sc, 1024, 768, 48, 5, 0)
+    b, sb = _render_flags(gpu, sc, 1024, 768, 48, 5, PT_FLAG_SEPARATE_KERNELS)
+    assert sa.ray_bounces == sb.ray_bounces and sa.passes == 2
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    m, sm = gpu_render(gpu, sc, 1024, 768, 48, 5, backend=ptlib.BACKEND_MEGAKERNEL)
+    assert sm.ray_bounces == sa.ray_bounces and np.array_equal(a.view(np.uint32), m.view(np.uint32))
