@@ -504,7 +504,14 @@ struct ShadeOut {
     uint32_t meta0, meta1;
     vec3 contrib;        // throughput * emission of the hit object (zero when it does not emit)
     bool emits;
+    bool deferred;       // kShadeDeferRefract only: the hit is on glass and was not shaded
 };
+
+// shade_hit variants.  A wave almost always holds at least one ray that hit the glass sphere, so the whole wave pays
+// for the refraction body (the longest of the three materials) on every chunk.  k_pass therefore shades with
+// kShadeDeferRefract - glass hits are only reported - collects them per wave in LDS and shades them 64 at a time
+// with kShadeRefractOnly: the same arithmetic per ray, executed by full waves.
+constexpr int kShadeAll = 0, kShadeDeferRefract = 1, kShadeRefractOnly = 2;
 
 // hit point, normal and material of a hit, as intersect_sphere / Triangle::intersect return them
 struct Surface {
@@ -536,10 +543,17 @@ __device__ __forceinline__ Surface fetch_surface(const DevScene &S, vec3 o, vec3
 }
 
 // One radiance() invocation after its intersect_scene call returned Some (mod.rs:665-789).
-template <class Params>
+template <int MODE = kShadeAll, class Params>
 __device__ __forceinline__ void shade_hit(const DevScene &S, const Params &F, const PathRay &in, HitRec h,
                                           ShadeOut &out) {
     const Surface sf = fetch_surface(S, in.o, in.d, h);
+    out.deferred = false;
+    if (MODE == kShadeDeferRefract && sf.reflect == kRefract) {
+        out.deferred = true;
+        out.n_rays = 0;
+        out.emits = false;
+        return;
+    }
     const vec3 d = in.d;
     const vec3 n = sf.n;
     const vec3 nl = dot(n, d) < 0.0f ? n : n * -1.0f;  // normal_towards_ray
@@ -565,7 +579,7 @@ __device__ __forceinline__ void shade_hit(const DevScene &S, const Params &F, co
     int n_rays = alive ? 1 : 0;
     vec3 d0 = d, thr0 = thr, d1 = d, thr1 = thr;
 
-    if (sf.reflect == kDiffuse) {  // mod.rs:687-715
+    if (MODE != kShadeRefractOnly && sf.reflect == kDiffuse) {  // mod.rs:687-715
         const float r1 = (2.0f * 3.141592653589793f) * unit_f32(rnd.b);
         const float r2 = unit_f32(rnd.c);
         const float r2s = f_sqrt(r2);
@@ -578,7 +592,7 @@ __device__ __forceinline__ void shade_hit(const DevScene &S, const Params &F, co
     } else {
         const vec3 refl = d - n * 2.0f * dot(n, d);  // mod.rs:722-723 / 733-734
         d0 = refl;
-        if (sf.reflect == kRefract) {  // mod.rs:729-788
+        if (MODE == kShadeRefractOnly || sf.reflect == kRefract) {  // mod.rs:729-788
             const bool into = dot(n, nl) > 0.0f;
             const float nc = 1.0f, nt = 1.5f;
             const float nnt = into ? nc / nt : nt / nc;
