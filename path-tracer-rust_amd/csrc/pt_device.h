@@ -50,7 +50,8 @@ struct alignas(16) ObjPairRec {
     uint32_t pair_count[2];
     int32_t bvh_root[2];
     uint32_t obj[2];            // object index
-    uint32_t pad[2];
+    uint32_t admit[2];          // mesh whose bounding sphere is so large that a wave of rays practically never misses
+                                // it as a whole: the speculative scan skips the gate arithmetic (see scan_scene)
 };
 
 // Two consecutive triangles of one mesh (world space), component by component, read with a wave-uniform
@@ -382,7 +383,8 @@ __host__ __device__ inline size_t bvh_lds_bytes(const DevScene &S, uint32_t bloc
 //   intersect_sphere(...).is_some() (mod.rs:267-273).  intersect_scene_dev verifies the winner afterwards.
 template <bool BVH, bool EXACT_GATES>
 __device__ __forceinline__ void consider_object(const DevScene &S, const ObjPairRec &ob, int hf, float b, float det,
-                                                vec3 o, vec3 d, uint4 *lds, float &best_t, int32_t &best_id) {
+                                                vec3 o, vec3 d, uint4 *lds, float &best_t, int32_t &best_id,
+                                                bool admit = false) {
     const float eps = 1e-4f;
     bool sph_hit;
     if (ob.kind[hf] == kKindSphere) {
@@ -401,10 +403,10 @@ __device__ __forceinline__ void consider_object(const DevScene &S, const ObjPair
         const float sq = f_sqrt(det);
         sph_hit = !(det < 0.0f) && ((b - sq) >= eps || (b + sq) >= eps);
     } else {
-        sph_hit = !(det < 0.0f);
+        sph_hit = admit || !(det < 0.0f);
     }
     // bounding-sphere gate (mod.rs:267-273): skip the triangle list when no lane passes
-    if (__builtin_amdgcn_ballot_w64(sph_hit) == 0ull) return;
+    if (!admit && __builtin_amdgcn_ballot_w64(sph_hit) == 0ull) return;
     float mt = __builtin_inff();
     int32_t mid = -1;
     const int32_t root = ob.bvh_root[hf];
@@ -452,12 +454,21 @@ __device__ __forceinline__ HitRec scan_scene(const DevScene &S, vec3 o, vec3 d, 
     const uint32_t n_pairs = (S.n_objs + 1u) >> 1;
     for (uint32_t p = 0; p < n_pairs; ++p) {
         const ObjPairRec ob = ld_uniform(S.obj_pairs + p);  // wave-uniform -> scalar loads
+        // Speculative pass: a mesh flagged `admit` goes straight to its triangles.  Admitting more meshes than the
+        // reference keeps the argument of intersect_scene_dev intact (winner over a superset, verified afterwards);
+        // what it saves is the gate arithmetic of spheres that no wave ever misses (the walls of a room).
+        const bool a0 = !EXACT_GATES && ob.admit[0] != 0u, a1 = !EXACT_GATES && ob.admit[1] != 0u;
+        if (a0 && a1) {  // wave-uniform
+            consider_object<BVH, EXACT_GATES>(S, ob, 0, 0.0f, 0.0f, o, d, lds, best_t, best_id, true);
+            consider_object<BVH, EXACT_GATES>(S, ob, 1, 0.0f, 0.0f, o, d, lds, best_t, best_id, true);
+            continue;
+        }
         // intersect_sphere's discriminant (mod.rs:413-416) for both objects of the pair
         const f32x2 opx = ld2(ob.cx) - ox2, opy = ld2(ob.cy) - oy2, opz = ld2(ob.cz) - oz2;
         const f32x2 b = (opx * dx2 + opy * dy2) + opz * dz2;
         const f32x2 det = (b * b - ((opx * opx + opy * opy) + opz * opz)) + ld2(ob.rr);
-        consider_object<BVH, EXACT_GATES>(S, ob, 0, b[0], det[0], o, d, lds, best_t, best_id);
-        consider_object<BVH, EXACT_GATES>(S, ob, 1, b[1], det[1], o, d, lds, best_t, best_id);
+        consider_object<BVH, EXACT_GATES>(S, ob, 0, b[0], det[0], o, d, lds, best_t, best_id, a0);
+        consider_object<BVH, EXACT_GATES>(S, ob, 1, b[1], det[1], o, d, lds, best_t, best_id, a1);
     }
     HitRec h;
     h.t = best_t;

@@ -345,12 +345,17 @@ bool flatten_scene(const pt_camera &cam, const pt_object *objs, uint32_t n_objs,
             pr.pair_count[hf] = r.pair_count;
             pr.bvh_root[hf] = r.bvh_root;
             pr.obj[hf] = n_objs - 1u - v;
+            // A gate pays when a whole wave of 64 unrelated rays misses the sphere, i.e. when a single ray hits it
+            // with probability well under 1/64: roughly (radius / distance)^2 / 4 with distances of the order of the
+            // scene.  Spheres above an eighth of the scene diagonal are not worth their arithmetic.
+            pr.admit[hf] = (r.kind == kKindMesh && r.rr > (scene_R * 0.125f) * (scene_R * 0.125f)) ? 1u : 0u;
         } else {  // filler: a sphere whose discriminant is -inf for every finite ray
             pr.cx[hf] = pr.cy[hf] = pr.cz[hf] = 0.0f;
             pr.rr[hf] = -std::numeric_limits<float>::infinity();
             pr.kind[hf] = kKindSphere;
             pr.bvh_root[hf] = kNoBvh;
             pr.obj[hf] = 0;
+            pr.admit[hf] = 0u;
         }
     }
     return true;
