@@ -210,6 +210,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, ShadeParams F, Ray
 // write and re-read of the primary rays, and it lets streams that are intersecting (VALU-bound) share a CU with
 // streams that are waiting on their queue loads.  The accumulators stay in LDS for the whole pass and are flushed
 // once.  Scenes with a BVH keep the three-kernel form (their intersect step wants 512-thread workgroups).
+template <bool DEFER>
 __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, RayQueue q0, RayQueue q1, uint32_t cap,
                                                  uint32_t s0, uint32_t s_here, uint32_t m,
                                                  unsigned long long *__restrict__ acc,
@@ -336,14 +337,14 @@ __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, R
                 if (h.id >= 0) {
                     in.pix = lds_pix[word_pix(word)];
                     in.meta = pack_meta(s0 + word_sample(word), word_depth(word), word_branch(word));
-                    shade_hit<kShadeDeferRefract>(S, P, in, h, so);
+                    shade_hit<DEFER ? kShadeDeferRefract : kShadeAll>(S, P, in, h, so);
                     if (so.emits) add_radiance_lds(lds_acc, m, word_pix(word), so.contrib);
                 }
             }
             append(so, word);
             // glass hits wait in this wave's LDS buffer until there are 64 of them
-            const uint64_t md = __builtin_amdgcn_ballot_w64(so.deferred);
-            if (md != 0ull) {
+            const uint64_t md = DEFER ? __builtin_amdgcn_ballot_w64(so.deferred) : 0ull;
+            if (DEFER && md != 0ull) {
                 if (so.deferred) {
                     const uint32_t e = n_defer + lane_prefix(md);
                     dbuf[e] = make_float4(in.o.x, in.o.y, in.o.z, in.d.x);
@@ -352,12 +353,12 @@ __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, R
                 }
                 n_defer += (uint32_t)__builtin_popcountll(md);
             }
-            if (n_defer >= 64u) {  // wave-uniform
+            if (DEFER && n_defer >= 64u) {  // wave-uniform
                 n_defer -= 64u;
                 shade_deferred(n_defer + (tid & 63u), true);
             }
         }
-        if (n_defer != 0u) {  // the rest of this wave's glass hits of the level (carrying them over would let a few
+        if (DEFER && n_defer != 0u) {  // the rest of this wave's glass hits of the level (carrying them over would let a few
                               // late rays stretch the stream by many nearly empty levels: measured 23.4 against 29.3)
             shade_deferred(tid & 63u, (tid & 63u) < n_defer);
             n_defer = 0u;
@@ -593,8 +594,17 @@ void launch_shade(hipStream_t st, uint32_t K, const DevScene &S, const FramePara
 void launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const FrameParams &F, const RayQueue &q0,
                  const RayQueue &q1, uint32_t cap, uint32_t s0, uint32_t s_here, uint32_t m, unsigned long long *acc,
                  unsigned long long *blk_rays, uint32_t *flags) {
-    const size_t lds = pass_lds_defer_offset(m) + (size_t)(kBlock / 64u) * 3u * kDeferCap * sizeof(float4);
-    hipLaunchKernelGGL(k_pass, dim3(K), dim3(kBlock), lds, st, S, F, q0, q1, cap, s0, s_here, m, acc, blk_rays, flags);
+    // The deferral buffers are 24 KB per workgroup: worth it while 5-6 workgroups still fit a CU's 160 KB of LDS (the
+    // accumulators of a stream take 28 B per pixel); frames so large that a stream owns hundreds of pixels (4096^2:
+    // 1024) shade every material in place instead.
+    const size_t lds_plain = pass_lds_defer_offset(m);
+    const size_t lds_defer = lds_plain + (size_t)(kBlock / 64u) * 3u * kDeferCap * sizeof(float4);
+    if (lds_defer <= 32u * 1024u)
+        hipLaunchKernelGGL(k_pass<true>, dim3(K), dim3(kBlock), lds_defer, st, S, F, q0, q1, cap, s0, s_here, m, acc,
+                           blk_rays, flags);
+    else
+        hipLaunchKernelGGL(k_pass<false>, dim3(K), dim3(kBlock), lds_plain, st, S, F, q0, q1, cap, s0, s_here, m, acc,
+                           blk_rays, flags);
 }
 void launch_scatter_chunks(hipStream_t st, const float *src, float *dst, uint32_t npix, uint32_t C, uint32_t n,
                            uint32_t j) {
