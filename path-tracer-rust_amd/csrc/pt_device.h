@@ -35,7 +35,9 @@ struct alignas(16) ObjRec {
     uint32_t pair_begin;  // first TriPairRec of the mesh
     uint32_t pair_count;  // number of TriPairRec of the mesh (>= (tri_count+1)/2; BVH leaves may be half full)
     int32_t bvh_root;     // kNoBvh, or the root reference of the mesh's BVH (>= 0 node index, < 0: ~pair index)
-    uint32_t pad0, pad1;
+    float rr_in;          // mesh: a point of the ray within sqrt(rr_in) of the sphere's centre proves the gate passes
+                          // (intersect_scene_dev); negative when no such shortcut is offered
+    uint32_t pad1;
 };
 
 // Two consecutive objects of the scene in the order intersect_scene visits them (reverse index order: half 0
@@ -468,7 +470,8 @@ __device__ __forceinline__ HitRec scan_scene(const DevScene &S, vec3 o, vec3 d, 
         const f32x2 b = (opx * dx2 + opy * dy2) + opz * dz2;
         const f32x2 det = (b * b - ((opx * opx + opy * opy) + opz * opz)) + ld2(ob.rr);
         consider_object<BVH, EXACT_GATES>(S, ob, 0, b[0], det[0], o, d, lds, best_t, best_id, a0);
-        consider_object<BVH, EXACT_GATES>(S, ob, 1, b[1], det[1], o, d, lds, best_t, best_id, a1);
+        if (2u * p + 1u < S.n_objs)  // the second half of the last pair of an odd scene is a filler (wave-uniform)
+            consider_object<BVH, EXACT_GATES>(S, ob, 1, b[1], det[1], o, d, lds, best_t, best_id, a1);
     }
     HitRec h;
     h.t = best_t;
@@ -489,11 +492,19 @@ __device__ __forceinline__ HitRec intersect_scene_dev(const DevScene &S, vec3 o,
     if (h.id >= (int32_t)S.n_objs) {
         const uint32_t owner = S.tri_shade[h.id - (int32_t)S.n_objs].owner;
         const ObjRec g = S.objs[owner];  // per-lane gather: the winner's bounding sphere
-        const vec3 op = mk(g.cx, g.cy, g.cz) - o;
-        const float b = dot(op, d);
-        const float det = b * b - dot(op, op) + g.rr;
-        const float sq = f_sqrt(det);
-        suspect = !(!(det < 0.0f) && ((b - sq) >= 1e-4f || (b + sq) >= 1e-4f));
+        // Usually the hit point lies well inside that sphere (it is a point of a triangle the sphere encloses): a point
+        // of the ray, ahead of the origin, deeper than 0.1 % of the radius inside the sphere means a chord long enough
+        // that the f32 gate - discriminant >= 0, far root >= 1e-4 - cannot fail (pt_host.cpp sets rr_in with the
+        // margins, or -1).  Only when some lane cannot show that is the gate evaluated as the reference does.
+        const vec3 pc = (o + d * h.t) - mk(g.cx, g.cy, g.cz);
+        const bool deep = dot(pc, pc) <= g.rr_in;  // false on NaN
+        if (__builtin_amdgcn_ballot_w64(!deep) != 0ull) {
+            const vec3 op = mk(g.cx, g.cy, g.cz) - o;
+            const float b = dot(op, d);
+            const float det = b * b - dot(op, op) + g.rr;
+            const float sq = f_sqrt(det);
+            suspect = !(!(det < 0.0f) && ((b - sq) >= 1e-4f || (b + sq) >= 1e-4f));
+        }
     }
     if (__builtin_amdgcn_ballot_w64(suspect) != 0ull) h = scan_scene<BVH, true>(S, o, d, lds);
     return h;

@@ -224,6 +224,7 @@ bool flatten_scene(const pt_camera &cam, const pt_object *objs, uint32_t n_objs,
             r.cy = position.y;
             r.cz = position.z;
             r.rr = o.radius * o.radius;  // radius.powi(2), mod.rs:416
+            r.rr_in = -1.0f;
             r.tri_begin = 0;
             r.tri_count = 0;
             r.pair_begin = 0;
@@ -239,6 +240,22 @@ bool flatten_scene(const pt_camera &cam, const pt_object *objs, uint32_t n_objs,
             r.cy = gate.y;
             r.cz = gate.z;
             r.rr = o.bs_radius * o.bs_radius;
+            {
+                // rr_in: see intersect_scene_dev.  A point of the ray, ahead of the origin, within (1 - eta) r of the
+                // centre with eta = 1e-3: the chord through it is >= 0.09 r long, so the exact discriminant is
+                // >= 2e-3 r^2 and the far root lies >= 1e-3 r ahead of the origin.  With every origin within 4 r of the
+                // centre (origins lie in the scene's bounding box) the f32 discriminant is off by <= 4 e (16+16+1) r^2
+                // ~ 8e-6 r^2, its root by <= 9e-5 r, so the computed far root is >= 9e-4 r >= 1e-4 for r >= 0.2: the
+                // gate passes.  The factor 0.998 and the absolute term cover the device's own o + d*t and distance.
+                const float rad = f_abs(o.bs_radius);
+                float far2 = 0.0f;  // squared distance from the centre to the farthest corner of the scene's box
+                for (int k = 0; k < 8; ++k) {
+                    const vec3 corner = mk((k & 1) ? shi.x : slo.x, (k & 2) ? shi.y : slo.y, (k & 4) ? shi.z : slo.z);
+                    far2 = f_max(far2, dot(corner - gate, corner - gate));
+                }
+                const bool offer = std::isfinite(rad) && rad >= 0.2f && far2 <= 16.0f * rad * rad;
+                r.rr_in = offer ? r.rr * 0.998f - 1e-4f * (1.0f + rad) : -1.0f;
+            }
             r.tri_begin = o.tri_offset;
             r.tri_count = o.tri_count;
             r.pair_begin = (uint32_t)out.tri_pairs.size();

@@ -50,6 +50,25 @@ __device__ __forceinline__ void store_ray(const RayQueue &q, size_t at, vec3 o, 
     q.tp[at] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(word));
 }
 
+// One stream's slice of a queue, addressed by 32-bit byte offsets from scalar base pointers (slot * 16 / 8 fits 32 bits:
+// cap < 2^27): the loads and stores then take the base from an SGPR pair and one VGPR offset instead of a 64-bit
+// address computed per lane.
+struct StreamSlice {
+    char *od0, *od1, *tp;
+};
+__device__ __forceinline__ StreamSlice slice_of(const RayQueue &q, size_t base) {
+    StreamSlice s;
+    s.od0 = reinterpret_cast<char *>(q.od0 + base);
+    s.od1 = reinterpret_cast<char *>(q.od1 + base);
+    s.tp = reinterpret_cast<char *>(q.tp + base);
+    return s;
+}
+__device__ __forceinline__ void store_ray(const StreamSlice &q, uint32_t slot, vec3 o, vec3 d, vec3 thr, uint32_t word) {
+    *reinterpret_cast<float4 *>(q.od0 + slot * 16u) = make_float4(o.x, o.y, o.z, d.x);
+    *reinterpret_cast<float2 *>(q.od1 + slot * 8u) = make_float2(d.y, d.z);
+    *reinterpret_cast<float4 *>(q.tp + slot * 16u) = make_float4(thr.x, thr.y, thr.z, __uint_as_float(word));
+}
+
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_generate(FrameParams F, RayQueue q, uint32_t *__restrict__ cnt0,
                                                      uint32_t cap, uint32_t s0, uint32_t s_here, uint32_t m) {
@@ -246,11 +265,10 @@ __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, R
     float4 *const dbuf = reinterpret_cast<float4 *>(reinterpret_cast<char *>(dyn_lds) + pass_lds_defer_offset(m)) +
                          (size_t)(tid >> 6) * (3u * kDeferCap);
     uint32_t n_defer = 0;  // wave-uniform
-    const RayQueue *qout_p = nullptr;
+    StreamSlice qout{};  // this stream's slice of the level's output container
     uint32_t *tail_p = nullptr;
     // stream compaction: survivors first (path order kept inside the wave), split children after them
     auto append = [&](const ShadeOut &so, uint32_t word) {
-        const RayQueue &qout = *qout_p;
         const uint64_t m1 = __builtin_amdgcn_ballot_w64(so.n_rays >= 1);
         const uint64_t m2 = __builtin_amdgcn_ballot_w64(so.n_rays == 2);
         const uint32_t c1 = (uint32_t)__builtin_popcountll(m1), c2 = (uint32_t)__builtin_popcountll(m2);
@@ -261,7 +279,7 @@ __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, R
         if (so.n_rays >= 1) {
             const uint32_t slot = wbase + lane_prefix(m1);
             if (slot < cap)
-                store_ray(qout, base + slot, so.x, so.d0, so.thr0,
+                store_ray(qout, slot, so.x, so.d0, so.thr0,
                           pack_word(word_pix(word), word_sample(word), meta_depth(so.meta0), meta_branch(so.meta0)));
             else
                 overflow = true;
@@ -269,7 +287,7 @@ __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, R
         if (so.n_rays == 2) {
             const uint32_t slot = wbase + c1 + lane_prefix(m2);
             if (slot < cap)
-                store_ray(qout, base + slot, so.x, so.d1, so.thr1,
+                store_ray(qout, slot, so.x, so.d1, so.thr1,
                           pack_word(word_pix(word), word_sample(word), meta_depth(so.meta1), meta_branch(so.meta1)));
             else
                 overflow = true;
@@ -299,13 +317,13 @@ __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, R
         append(so, word);
     };
     for (uint32_t depth = 0; depth < (uint32_t)kMaxDepth && n != 0u; ++depth) {
-        const RayQueue qin = (depth & 1u) ? q1 : q0, qout = (depth & 1u) ? q0 : q1;  // level 0 is never stored
+        const StreamSlice qin = slice_of((depth & 1u) ? q1 : q0, base);  // level 0 is never stored
+        qout = slice_of((depth & 1u) ? q0 : q1, base);
         __syncthreads();  // level `depth` of the stream is complete and visible to the whole workgroup
         // the other counter was last read before this barrier (end of the level before) and is next added to after
         // the next one
         if (tid == 0) s_tail_p[(depth + 1u) & 1u] = 0u;
         tail_p = s_tail_p + (depth & 1u);
-        qout_p = &qout;
         total += n;
         for (uint32_t j0 = 0; j0 < n; j0 += kBlock) {  // uniform trip count: every lane reaches the ballots
             const uint32_t i = j0 + tid;
@@ -317,8 +335,9 @@ __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, R
                     in = primary_ray(F, lds_pix[pj], s0 + sj);
                     word = pack_word(pj, sj, 0u, 1u);
                 } else {
-                    const float4 a = qin.od0[base + i], tp = qin.tp[base + i];
-                    const float2 c = qin.od1[base + i];
+                    const float4 a = *reinterpret_cast<const float4 *>(qin.od0 + i * 16u);
+                    const float4 tp = *reinterpret_cast<const float4 *>(qin.tp + i * 16u);
+                    const float2 c = *reinterpret_cast<const float2 *>(qin.od1 + i * 8u);
                     in.o = mk(a.x, a.y, a.z);
                     in.d = mk(a.w, c.x, c.y);
                     in.thr = mk(tp.x, tp.y, tp.z);
