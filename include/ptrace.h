@@ -171,7 +171,12 @@ int pt_ctx_set_profiling(pt_ctx *ctx, int enabled);
 /* Single-ray queries through the same device intersection code (a6): the callers are object
  * picking / click-debug / orbit pivot (src/views/viewport_tab.rs:240-246, render_tab.rs:177-205).
  * Host arrays: o,d = n*3 floats; outputs may be NULL.  object_id = -1 on a miss
- * (intersect_scene -> None), tri_id = index into the object's triangle list or -1 for spheres. */
+ * (intersect_scene -> None), tri_id = index into the object's triangle list or -1 for spheres.
+ * Bit-for-bit agreement with the reference's intersect_scene is guaranteed for rays that start where the path
+ * tracer's own rays start - inside the bounding box of the scene's objects and of the camera given to
+ * pt_ctx_set_scene: the error bounds behind the BVH boxes and the bounding-sphere shortcuts assume that distance
+ * scale (pt_host.cpp).  A picking ray from a camera far outside the scene still gets the nearest hit, but a hit that
+ * only exists through f32 round-off of the reference's arithmetic at that distance may be resolved differently. */
 int pt_ctx_intersect(pt_ctx *ctx, const float *o, const float *d, uint32_t n, float *t,
                      int32_t *object_id, int32_t *tri_id, float *x, float *normal);
 

@@ -655,3 +655,53 @@ def test_pass_kernel_full_size(gpu):
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     m, sm = gpu_render(gpu, sc, 1024, 768, 48, 5, backend=ptlib.BACKEND_MEGAKERNEL)
     assert sm.ray_bounces == sa.ray_bounces and np.array_equal(a.view(np.uint32), m.view(np.uint32))
+
+
+def test_gate_shortcut_at_the_rim(gpu):
+    """The winner's bounding-sphere gate is skipped when the hit point lies well inside the sphere (rr_in,
+    intersect_scene_dev).  Meshes whose stored sphere does not enclose them - small, large, off-centre - with rays
+    aimed at the rim of the sphere on the mesh, from inside and outside the sphere, towards and away from it: hit
+    or miss, distance, triangle, point and normal must be the oracle's, bit for bit."""
+    L, ctx = gpu
+    O = ptlib.oracle()
+    cam = ptlib.make_camera((0, 0, 3), (0, 0, -1))
+    rng = np.random.default_rng(123)
+    quad = [ptlib.make_tri((-2, -2, 0), (2, -2, 0), (2, 2, 0)), ptlib.make_tri((-2, -2, 0), (2, 2, 0), (-2, 2, 0))]
+    for (centre, radius) in (((0.0, 0.0, 0.0), 1.5), ((0.4, -0.3, 0.2), 1.1), ((0.0, 0.0, 0.0), 3.5),
+                             ((1.0, 1.0, -0.5), 2.0)):
+        sc = ptlib.Scene("rim", cam, [ptlib.make_mesh((0, 0, 0), (0.9, 0.9, 0.9), (0, 0, 0), "Diffuse", 0, 2, centre,
+                                                      radius)], quad)
+        set_scene(gpu, sc)
+        n = 200000
+        c = np.array(centre, np.float32)
+        # targets on the quad plane at distances around the circle where the sphere cuts the plane
+        rho = np.sqrt(max(radius * radius - float(c[2]) ** 2, 1e-3))
+        ang = rng.uniform(0, 2 * np.pi, n)
+        rr = rho * (1.0 + rng.choice([0.0, 1e-7, -1e-7, 1e-4, -1e-4, 1e-3, -1e-3, 2e-3, -2e-3, 0.05, -0.5], n)
+                    + rng.normal(0, 1e-6, n))
+        tgt = np.stack([c[0] + rr * np.cos(ang), c[1] + rr * np.sin(ang), np.zeros(n)], 1)
+        org = np.stack([rng.uniform(-2, 2, n), rng.uniform(-2, 2, n), rng.choice([3.0, 0.5, 1e-3, -1.0, 2.9], n)], 1)
+        d = tgt - org
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        d[::7] *= -1.0  # some rays point away from the plane
+        o = np.ascontiguousarray(org.astype(np.float32))
+        d = np.ascontiguousarray(d.astype(np.float32))
+        ps = sc.pto()
+
+        def run(fn, handle):
+            t = np.zeros(n, np.float32)
+            oid = np.zeros(n, np.int32)
+            tid = np.zeros(n, np.int32)
+            x = np.zeros((n, 3), np.float32)
+            nr = np.zeros((n, 3), np.float32)
+            rc = fn(handle, _np_f(o), _np_f(d), n, _np_f(t), oid.ctypes.data_as(ptlib.i32p),
+                    tid.ctypes.data_as(ptlib.i32p), _np_f(x), _np_f(nr))
+            return rc, t, oid, tid, x
+
+        rc, t, oid, tid, x = run(L.pt_ctx_intersect, ctx)
+        assert rc == 0, L.pt_last_error()
+        _, t0, oid0, tid0, x0 = run(O.pto_intersect_batch, C.byref(ps))
+        assert 0.05 < (oid0 >= 0).mean() < 0.95  # both outcomes are well represented
+        assert np.array_equal(oid, oid0) and np.array_equal(tid, tid0)
+        assert np.array_equal(t.view(np.uint32), t0.view(np.uint32))
+        assert np.array_equal(x.view(np.uint32), x0.view(np.uint32))
