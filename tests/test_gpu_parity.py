@@ -705,3 +705,80 @@ def test_gate_shortcut_at_the_rim(gpu):
         assert np.array_equal(oid, oid0) and np.array_equal(tid, tid0)
         assert np.array_equal(t.view(np.uint32), t0.view(np.uint32))
         assert np.array_equal(x.view(np.uint32), x0.view(np.uint32))
+
+
+def _random_scene(rng, k):
+    """A random room: spheres of all three materials (some emissive, some huge, some touching), meshes of 1-40
+    triangles (axis-aligned quads, slivers, soups) with Mesh::new's bounding sphere, a lying one, or a loose one."""
+    cam = ptlib.make_camera((float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1)), float(rng.uniform(3, 7))),
+                            (float(rng.uniform(-0.2, 0.2)), float(rng.uniform(-0.2, 0.2)), -1.0))
+    mats = ["Diffuse", "Specular", "Refract"]
+    objs, tris = [], []
+    for _ in range(int(rng.integers(0, 6))):
+        r = float(rng.choice([0.3, 0.8, 1.5, 25.0]))
+        pos = tuple(float(v) for v in rng.uniform(-3, 3, 3))
+        em = tuple(float(v) for v in (rng.uniform(0, 6, 3) if rng.random() < 0.4 else np.zeros(3)))
+        col = tuple(float(v) for v in rng.uniform(0.05, 0.999, 3))
+        objs.append(ptlib.make_sphere(pos, r, col, em, mats[int(rng.integers(0, 3))]))
+    for _ in range(int(rng.integers(1, 7))):
+        n = int(rng.choice([1, 2, 2, 2, 5, 17, 40]))
+        base = len(tris)
+        if n == 2:  # a wall
+            ax = int(rng.integers(0, 3))
+            sx, sy = float(rng.uniform(1, 6)), float(rng.uniform(1, 6))
+            v = np.zeros((4, 3), np.float32)
+            for i in range(2):
+                for j in range(2):
+                    v[2 * i + j][(ax + 1) % 3] = -sx if i == 0 else sx
+                    v[2 * i + j][(ax + 2) % 3] = -sy if j == 0 else sy
+            local = [(v[0], v[1], v[2]), (v[2], v[1], v[3])]
+        else:
+            c0 = rng.uniform(-1, 1, 3)
+            local = [tuple(c0 + rng.normal(0, rng.choice([0.02, 0.5, 1.5]), 3) for _ in range(3)) for _ in range(n)]
+        for (a, b, c) in local:
+            tris.append(ptlib.make_tri(tuple(map(float, a)), tuple(map(float, b)), tuple(map(float, c))))
+        pts = np.array([p for t in local for p in t], np.float32)
+        lo, hi = pts.min(0), pts.max(0)
+        centre = lo + hi * np.float32(0.5)  # Mesh::new's centre (mod.rs:463)
+        radius = float(max(np.linalg.norm(lo - centre), np.linalg.norm(hi - centre)))
+        mode = rng.random()
+        if mode < 0.25:  # a sphere that does not enclose the mesh (stored spheres are used verbatim)
+            centre, radius = centre + rng.normal(0, 0.5, 3).astype(np.float32), radius * float(rng.uniform(0.2, 0.7))
+        elif mode < 0.4:
+            radius *= 3.0
+        pos = tuple(float(v) for v in rng.uniform(-3, 3, 3))
+        em = tuple(float(v) for v in (rng.uniform(0, 3, 3) if rng.random() < 0.3 else np.zeros(3)))
+        col = tuple(float(v) for v in rng.uniform(0.05, 0.999, 3))
+        objs.append(ptlib.make_mesh(pos, col, em, mats[int(rng.integers(0, 3))], base, n,
+                                    tuple(float(v) for v in centre), max(radius, 1e-3)))
+    order = rng.permutation(len(objs))
+    return ptlib.Scene("fuzz%d" % k, cam, [objs[i] for i in order], tris)
+
+
+def test_random_scenes_against_oracle(gpu):
+    """40 random scenes through every device path (k_pass, separate kernels, megakernel, with and without the
+    acceleration structures): bounce counts equal the oracle's exactly, images within the tolerance, and the device
+    paths agree with each other bit for bit."""
+    rng = np.random.default_rng(2026)
+    total = 0
+    for k in range(40):
+        sc = _random_scene(rng, k)
+        w, h, spp = 40, 28, 6
+        want, cnt, _ = ptlib.oracle_render(sc, w, h, spp, 100 + k)
+        ref_img = None
+        for (backend, flags) in ((0, 0), (0, PT_FLAG_SEPARATE_KERNELS), (0, 1), (1, 0)):
+            L, _ = gpu
+            cfg = PtConfig(w, h, spp, backend, 100 + k, 0, 0, 0, flags)
+            out = np.zeros((w * h, 3), dtype=np.float32)
+            st = PtStats()
+            rc = L.pt_render(C.byref(cfg), C.byref(sc.cam), sc.objs, sc.n_objs, sc.tris, sc.n_tris, _np_f(out), None,
+                             None, None, C.byref(st))
+            assert rc == 0, L.pt_last_error()
+            assert st.ray_bounces == cnt.ray_bounces, (k, backend, flags)
+            assert float(np.abs(out - want).max()) <= TOL, (k, backend, flags)
+            if ref_img is None:
+                ref_img = out
+            else:
+                assert np.array_equal(out.view(np.uint32), ref_img.view(np.uint32)), (k, backend, flags)
+        total += cnt.ray_bounces
+    assert total > 100000
