@@ -111,7 +111,7 @@ struct DevScene {
     uint32_t n_objs;
     uint32_t n_tris;
     uint32_t n_bvh_nodes;  // 0: no mesh of the scene has a BVH (or BVH use is switched off for this frame)
-    uint32_t bvh_in_lds;   // nodes are staged in LDS (n_bvh_nodes <= kBvhMaxLdsNodes)
+    uint32_t bvh_in_lds;   // bit 0: nodes are staged in LDS; bit 1: child references fit 16 bits (u16 traversal stacks)
     uint32_t bvh_pair_base;  // first TriPairRec that is a BVH leaf (leaf references on a u16 stack are relative to it)
 };
 
@@ -366,7 +366,7 @@ __device__ __forceinline__ void bvh_closest(const DevScene &S, NodePtr nodes, Co
 // LDS carve-up of the kernels that intersect: [BvhNode x n_bvh_nodes][u16 stack: kBvhStack x blockDim] when the
 // nodes are staged, else [u32 stack: kBvhStack x blockDim] alone (nodes read from global memory)
 __device__ __forceinline__ void stage_bvh(const DevScene &S, uint4 *lds) {
-    if (S.n_bvh_nodes != 0u && S.bvh_in_lds != 0u) {
+    if (S.n_bvh_nodes != 0u && (S.bvh_in_lds & 1u) != 0u) {
         const uint4 *src = reinterpret_cast<const uint4 *>(S.bvh_nodes);
         for (uint32_t i = threadIdx.x; i < S.n_bvh_nodes * 4u; i += blockDim.x) lds[i] = src[i];
         __syncthreads();
@@ -374,19 +374,41 @@ __device__ __forceinline__ void stage_bvh(const DevScene &S, uint4 *lds) {
 }
 __host__ __device__ inline size_t bvh_lds_bytes(const DevScene &S, uint32_t block) {
     if (S.n_bvh_nodes == 0u) return 0;
-    return S.bvh_in_lds ? (size_t)S.n_bvh_nodes * sizeof(BvhNode) + (size_t)kBvhStack * block * sizeof(uint16_t)
-                        : (size_t)kBvhStack * block * sizeof(uint32_t);
+    return ((S.bvh_in_lds & 1u) ? (size_t)S.n_bvh_nodes * sizeof(BvhNode) : 0u) +
+           (size_t)kBvhStack * block * ((S.bvh_in_lds & 2u) ? sizeof(uint16_t) : sizeof(uint32_t));
 }
+
+#if defined(__HIPCC__)
+// one lane's walk of one mesh, with the node storage and stack width the scene was set up for
+__device__ __forceinline__ void bvh_walk(const DevScene &S, uint4 *lds, vec3 o, vec3 d, int32_t root, float best_t,
+                                         float &mt, int32_t &mid) {
+    uint4 *const stacks = (S.bvh_in_lds & 1u) ? lds + S.n_bvh_nodes * 4u : lds;
+    if (S.bvh_in_lds & 2u) {
+        uint16_t *stack = reinterpret_cast<uint16_t *>(stacks) + threadIdx.x;
+        Stack16 codec;
+        codec.pair_base = S.bvh_pair_base;
+        if (S.bvh_in_lds & 1u)
+            bvh_closest(S, reinterpret_cast<const BvhNode *>(lds), codec, stack, blockDim.x, o, d, root, best_t, mt, mid);
+        else
+            bvh_closest(S, S.bvh_nodes, codec, stack, blockDim.x, o, d, root, best_t, mt, mid);
+    } else {
+        uint32_t *stack = reinterpret_cast<uint32_t *>(stacks) + threadIdx.x;
+        bvh_closest(S, S.bvh_nodes, Stack32(), stack, blockDim.x, o, d, root, best_t, mt, mid);
+    }
+}
+#endif
 
 // One object of a pair: the tail of SceneObjectData::intersect (mod.rs:261-280) + intersect_scene's replace
 // rule (mod.rs:649), given the sphere discriminant arithmetic (b, det) that was done packed for both halves.
 //   EXACT_GATES = false is the speculative pass: a mesh is admitted when its bounding-sphere discriminant is
 //   non-negative - a necessary condition of the gate that needs no square root - instead of the full
 //   intersect_sphere(...).is_some() (mod.rs:267-273).  intersect_scene_dev verifies the winner afterwards.
-template <bool BVH, bool EXACT_GATES>
+//   DEFER_WALK: a mesh with a BVH is not walked here; its gate is evaluated exactly and *want_walk reports whether
+//   the ray has to walk it (k_intersect<true> collects such rays and walks them in dense waves: walk_deferred).
+template <bool BVH, bool EXACT_GATES, bool DEFER_WALK = false>
 __device__ __forceinline__ void consider_object(const DevScene &S, const ObjPairRec &ob, int hf, float b, float det,
                                                 vec3 o, vec3 d, uint4 *lds, float &best_t, int32_t &best_id,
-                                                bool admit = false) {
+                                                bool admit = false, bool *want_walk = nullptr) {
     const float eps = 1e-4f;
     bool sph_hit;
     if (ob.kind[hf] == kKindSphere) {
@@ -399,6 +421,11 @@ __device__ __forceinline__ void consider_object(const DevScene &S, const ObjPair
             best_t = t;
             best_id = (int32_t)ob.obj[hf];
         }
+        return;
+    }
+    if (BVH && DEFER_WALK && ob.bvh_root[hf] != kNoBvh && S.n_bvh_nodes != 0u) {  // wave-uniform
+        const float sq = f_sqrt(det);
+        if (!(det < 0.0f) && ((b - sq) >= eps || (b + sq) >= eps)) *want_walk = true;
         return;
     }
     if (EXACT_GATES) {
@@ -414,16 +441,7 @@ __device__ __forceinline__ void consider_object(const DevScene &S, const ObjPair
     const int32_t root = ob.bvh_root[hf];
     if (BVH && root != kNoBvh && S.n_bvh_nodes != 0u) {
         if (sph_hit) {  // per lane: divergent traversal
-            if (S.bvh_in_lds) {
-                uint16_t *stack = reinterpret_cast<uint16_t *>(lds + S.n_bvh_nodes * 4u) + threadIdx.x;
-                Stack16 codec;
-                codec.pair_base = S.bvh_pair_base;
-                bvh_closest(S, reinterpret_cast<const BvhNode *>(lds), codec, stack, blockDim.x, o, d, root, best_t, mt,
-                            mid);
-            } else {
-                uint32_t *stack = reinterpret_cast<uint32_t *>(lds) + threadIdx.x;
-                bvh_closest(S, S.bvh_nodes, Stack32(), stack, blockDim.x, o, d, root, best_t, mt, mid);
-            }
+            bvh_walk(S, lds, o, d, root, best_t, mt, mid);
         }
     } else {
         const f32x2 ox2 = splat2(o.x), oy2 = splat2(o.y), oz2 = splat2(o.z);
@@ -447,8 +465,8 @@ __device__ __forceinline__ void consider_object(const DevScene &S, const ObjPair
 // mod.rs:637,649); inside a mesh the first triangle in list order wins ties (mod.rs:598).
 // `best` starts at +inf instead of Option::None: identical for every finite, non-NaN distance.
 // BVH = false compiles the traversal out (scenes without a BVH mesh keep the small register footprint).
-template <bool BVH, bool EXACT_GATES>
-__device__ __forceinline__ HitRec scan_scene(const DevScene &S, vec3 o, vec3 d, uint4 *lds) {
+template <bool BVH, bool EXACT_GATES, bool DEFER_WALK = false>
+__device__ __forceinline__ HitRec scan_scene(const DevScene &S, vec3 o, vec3 d, uint4 *lds, bool *want_walk = nullptr) {
     float best_t = __builtin_inff();
     int32_t best_id = -1;
     const f32x2 ox2 = splat2(o.x), oy2 = splat2(o.y), oz2 = splat2(o.z);
@@ -461,17 +479,17 @@ __device__ __forceinline__ HitRec scan_scene(const DevScene &S, vec3 o, vec3 d, 
         // what it saves is the gate arithmetic of spheres that no wave ever misses (the walls of a room).
         const bool a0 = !EXACT_GATES && ob.admit[0] != 0u, a1 = !EXACT_GATES && ob.admit[1] != 0u;
         if (a0 && a1) {  // wave-uniform
-            consider_object<BVH, EXACT_GATES>(S, ob, 0, 0.0f, 0.0f, o, d, lds, best_t, best_id, true);
-            consider_object<BVH, EXACT_GATES>(S, ob, 1, 0.0f, 0.0f, o, d, lds, best_t, best_id, true);
+            consider_object<BVH, EXACT_GATES, DEFER_WALK>(S, ob, 0, 0.0f, 0.0f, o, d, lds, best_t, best_id, true, want_walk);
+            consider_object<BVH, EXACT_GATES, DEFER_WALK>(S, ob, 1, 0.0f, 0.0f, o, d, lds, best_t, best_id, true, want_walk);
             continue;
         }
         // intersect_sphere's discriminant (mod.rs:413-416) for both objects of the pair
         const f32x2 opx = ld2(ob.cx) - ox2, opy = ld2(ob.cy) - oy2, opz = ld2(ob.cz) - oz2;
         const f32x2 b = (opx * dx2 + opy * dy2) + opz * dz2;
         const f32x2 det = (b * b - ((opx * opx + opy * opy) + opz * opz)) + ld2(ob.rr);
-        consider_object<BVH, EXACT_GATES>(S, ob, 0, b[0], det[0], o, d, lds, best_t, best_id, a0);
+        consider_object<BVH, EXACT_GATES, DEFER_WALK>(S, ob, 0, b[0], det[0], o, d, lds, best_t, best_id, a0, want_walk);
         if (2u * p + 1u < S.n_objs)  // the second half of the last pair of an odd scene is a filler (wave-uniform)
-            consider_object<BVH, EXACT_GATES>(S, ob, 1, b[1], det[1], o, d, lds, best_t, best_id, a1);
+            consider_object<BVH, EXACT_GATES, DEFER_WALK>(S, ob, 1, b[1], det[1], o, d, lds, best_t, best_id, a1, want_walk);
     }
     HitRec h;
     h.t = best_t;
@@ -485,9 +503,10 @@ __device__ __forceinline__ HitRec scan_scene(const DevScene &S, vec3 o, vec3 d, 
 // candidate - a sphere, or a triangle of a mesh whose exact gate passes - it IS the reference's winner.  Only the
 // winner's own gate has to be evaluated exactly (one square root per ray instead of one per mesh); when it fails for
 // some lane (rounding at the rim of a bounding sphere) the wave repeats the scan with exact gates.
-template <bool BVH>
-__device__ __forceinline__ HitRec intersect_scene_dev(const DevScene &S, vec3 o, vec3 d, uint4 *lds) {
-    HitRec h = scan_scene<BVH, false>(S, o, d, lds);
+template <bool BVH, bool DEFER_WALK = false>
+__device__ __forceinline__ HitRec intersect_scene_dev(const DevScene &S, vec3 o, vec3 d, uint4 *lds,
+                                                      bool *want_walk = nullptr) {
+    HitRec h = scan_scene<BVH, false, DEFER_WALK>(S, o, d, lds, want_walk);
     bool suspect = false;
     if (h.id >= (int32_t)S.n_objs) {
         const uint32_t owner = S.tri_shade[h.id - (int32_t)S.n_objs].owner;
@@ -506,8 +525,45 @@ __device__ __forceinline__ HitRec intersect_scene_dev(const DevScene &S, vec3 o,
             suspect = !(!(det < 0.0f) && ((b - sq) >= 1e-4f || (b + sq) >= 1e-4f));
         }
     }
-    if (__builtin_amdgcn_ballot_w64(suspect) != 0ull) h = scan_scene<BVH, true>(S, o, d, lds);
+    if (__builtin_amdgcn_ballot_w64(suspect) != 0ull) h = scan_scene<BVH, true, DEFER_WALK>(S, o, d, lds, want_walk);
     return h;
+}
+
+// The BVH walks of a ray whose other objects are done (best_t / best_id hold their winner): every mesh with a BVH, in
+// visiting order, exact gate first.  A triangle strictly closer than the best so far wins; one exactly as far would
+// need the reference's visiting order to decide - reported, and the caller repeats that ray with the in-order scan.
+__device__ __forceinline__ bool walk_deferred(const DevScene &S, vec3 o, vec3 d, uint4 *lds, float &best_t,
+                                              int32_t &best_id) {
+    bool tie = false;
+    const uint32_t n_pairs = (S.n_objs + 1u) >> 1;
+    for (uint32_t p = 0; p < n_pairs; ++p) {
+        const ObjPairRec ob = ld_uniform(S.obj_pairs + p);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int32_t root = ob.bvh_root[hf];
+            if (ob.kind[hf] != kKindMesh || root == kNoBvh) continue;  // wave-uniform
+            const vec3 op = mk(ob.cx[hf], ob.cy[hf], ob.cz[hf]) - o;   // intersect_sphere, mod.rs:413-427
+            const float b = dot(op, d);
+            const float det = (b * b - dot(op, op)) + ob.rr[hf];
+            const float sq = f_sqrt(det);
+            const bool pass = !(det < 0.0f) && ((b - sq) >= 1e-4f || (b + sq) >= 1e-4f);
+            if (__builtin_amdgcn_ballot_w64(pass) == 0ull) continue;
+            float mt = __builtin_inff();
+            int32_t mid = -1;
+            if (pass) {
+                bvh_walk(S, lds, o, d, root, best_t, mt, mid);
+            }
+            if (pass && mid >= 0) {
+                if (mt < best_t) {
+                    best_t = mt;
+                    best_id = (int32_t)S.n_objs + mid;
+                } else if (mt == best_t) {
+                    tie = true;
+                }
+            }
+        }
+    }
+    return tie;
 }
 
 // ---------------------------------------------------------------------------------------------

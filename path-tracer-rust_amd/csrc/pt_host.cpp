@@ -365,7 +365,8 @@ bool flatten_scene(const pt_camera &cam, const pt_object *objs, uint32_t n_objs,
             // A gate pays when a whole wave of 64 unrelated rays misses the sphere, i.e. when a single ray hits it
             // with probability well under 1/64: roughly (radius / distance)^2 / 4 with distances of the order of the
             // scene.  Spheres above an eighth of the scene diagonal are not worth their arithmetic.
-            pr.admit[hf] = (r.kind == kKindMesh && r.rr > (scene_R * 0.125f) * (scene_R * 0.125f)) ? 1u : 0u;
+            // (a mesh with a BVH keeps its gate: there it saves a whole walk, and the deferred walks need its result)
+            pr.admit[hf] = (r.kind == kKindMesh && r.bvh_root == kNoBvh && r.rr > (scene_R * 0.125f) * (scene_R * 0.125f)) ? 1u : 0u;
         } else {  // filler: a sphere whose discriminant is -inf for every finite ray
             pr.cx[hf] = pr.cy[hf] = pr.cz[hf] = 0.0f;
             pr.rr[hf] = -std::numeric_limits<float>::infinity();

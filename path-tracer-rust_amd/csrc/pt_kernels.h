@@ -8,7 +8,7 @@
 namespace pt {
 
 constexpr uint32_t kBlock = 256;    // 4 waves of 64
-constexpr uint32_t kBlockBvh = 512;  // workgroup of the intersect kernel when BVH nodes are staged in LDS
+constexpr uint32_t kBlockBvh = 256;  // workgroup of the intersect kernel of scenes with a BVH
 constexpr uint32_t kMaxStreamPixels = 1024;  // pixels owned by one stream (24 KiB of LDS accumulators at most)
 constexpr uint32_t kLevels = 13;    // ray depths 0..11 plus the (always empty) level written by the last shade
 

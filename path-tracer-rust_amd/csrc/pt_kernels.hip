@@ -87,21 +87,85 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams F, RayQueue q, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// The BVH variant runs 1024-thread workgroups: one LDS copy of the nodes then serves 16 waves, and the walk -
-// bound by LDS / leaf-fetch latency, not by issue slots - gets twice the waves per CU to hide it.
+// The BVH variant.  Only the rays that pass the bounding-sphere gate of a BVH mesh walk it - a fifth of the lanes on
+// mesh.json - and a walk is hundreds of instructions, so walking inside the object loop ran the kernel's VALU at 21 %
+// lane occupancy (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU = 13.8 of 64).  Here the scan skips the walks
+// (intersect_scene_dev<true, true>: gates evaluated exactly, want_walk reported), rays that need one are parked per
+// wave in LDS (ray, best hit so far, ray index: 36 B) and walked 64 at a time (walk_deferred): full waves.
+constexpr uint32_t kParkCap = 128;  // 63 left over + 64 new at most
+__host__ __device__ inline size_t bvh_park_offset(const DevScene &S, uint32_t block) {
+    return (bvh_lds_bytes(S, block) + 15) & ~(size_t)15;
+}
+__host__ __device__ inline size_t bvh_park_bytes(uint32_t block) { return (size_t)(block / 64u) * kParkCap * 36u; }
+
 template <bool BVH>
-__global__ __launch_bounds__(BVH ? kBlockBvh : kBlock, BVH ? 6 : 1) void k_intersect(DevScene S, RayQueue q, float2 *__restrict__ hit,
+__global__ __launch_bounds__(BVH ? kBlockBvh : kBlock, BVH ? 5 : 1) void k_intersect(DevScene S, RayQueue q, float2 *__restrict__ hit,
                                                       const uint32_t *__restrict__ cnt, uint32_t cap,
                                                       unsigned long long *__restrict__ blk_rays) {
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
     const uint32_t n = cnt[b];
     const size_t base = (size_t)b * cap;
-    if (BVH && n != 0u) stage_bvh(S, dyn_lds);
-    for (uint32_t i = tid; i < n; i += blockDim.x) {
-        const float4 a = q.od0[base + i];
-        const float2 c = q.od1[base + i];
-        const HitRec h = intersect_scene_dev<BVH>(S, mk(a.x, a.y, a.z), mk(a.w, c.x, c.y), dyn_lds);
-        hit[base + i] = make_float2(h.t, __int_as_float(h.id));
+    if (!BVH) {
+        for (uint32_t i = tid; i < n; i += blockDim.x) {
+            const float4 a = q.od0[base + i];
+            const float2 c = q.od1[base + i];
+            const HitRec h = intersect_scene_dev<false>(S, mk(a.x, a.y, a.z), mk(a.w, c.x, c.y), dyn_lds);
+            hit[base + i] = make_float2(h.t, __int_as_float(h.id));
+        }
+    } else {
+        if (n != 0u) stage_bvh(S, dyn_lds);
+        // this wave's parking area: float4 (o, d.x) | float4 (d.y, d.z, t, id) | u32 ray index
+        char *park = reinterpret_cast<char *>(dyn_lds) + bvh_park_offset(S, blockDim.x) + (size_t)(tid >> 6) * kParkCap * 36u;
+        float4 *const pa = reinterpret_cast<float4 *>(park), *const pb = pa + kParkCap;
+        uint32_t *const pi = reinterpret_cast<uint32_t *>(pb + kParkCap);
+        const uint32_t lane = tid & 63u;
+        uint32_t n_park = 0;  // wave-uniform
+        auto walk = [&](uint32_t e, bool valid) {
+            if (valid) {
+                const float4 a = pa[e], bq = pb[e];
+                const uint32_t idx = pi[e];
+                const vec3 o = mk(a.x, a.y, a.z), d = mk(a.w, bq.x, bq.y);
+                float best_t = bq.z;
+                int32_t best_id = __float_as_int(bq.w);
+                if (walk_deferred(S, o, d, dyn_lds, best_t, best_id)) {  // a tie in distance: the in-order scan decides
+                    const HitRec h = scan_scene<true, true>(S, o, d, dyn_lds);
+                    best_t = h.t;
+                    best_id = h.id;
+                }
+                hit[base + idx] = make_float2(best_t, __int_as_float(best_id));
+            }
+        };
+        for (uint32_t j0 = 0; j0 < n; j0 += blockDim.x) {  // wave-uniform trip count
+            const uint32_t i = j0 + tid;
+            bool want = false;
+            vec3 o = mk(0, 0, 0), d = o;
+            HitRec h;
+            h.t = 0.0f;
+            h.id = -1;
+            if (i < n) {
+                const float4 a = q.od0[base + i];
+                const float2 c = q.od1[base + i];
+                o = mk(a.x, a.y, a.z);
+                d = mk(a.w, c.x, c.y);
+                h = intersect_scene_dev<true, true>(S, o, d, dyn_lds, &want);
+                if (!want) hit[base + i] = make_float2(h.t, __int_as_float(h.id));
+            }
+            const uint64_t mw = __builtin_amdgcn_ballot_w64(want);
+            if (mw != 0ull) {
+                if (want) {
+                    const uint32_t e = n_park + lane_prefix(mw);
+                    pa[e] = make_float4(o.x, o.y, o.z, d.x);
+                    pb[e] = make_float4(d.y, d.z, h.t, __int_as_float(h.id));
+                    pi[e] = i;
+                }
+                n_park += (uint32_t)__builtin_popcountll(mw);
+            }
+            if (n_park >= 64u) {
+                n_park -= 64u;
+                walk(n_park + lane, true);
+            }
+        }
+        if (n_park != 0u) walk(lane, lane < n_park);
     }
     if (tid == 0) blk_rays[b] += n;
 }
@@ -587,8 +651,8 @@ void launch_generate(hipStream_t st, uint32_t K, const FrameParams &F, const Ray
 void launch_intersect(hipStream_t st, uint32_t K, const DevScene &S, const RayQueue &q, float2 *hit,
                       const uint32_t *cnt, uint32_t cap, unsigned long long *blk_rays) {
     if (S.n_bvh_nodes != 0u)
-        hipLaunchKernelGGL(k_intersect<true>, dim3(K), dim3(kBlockBvh), bvh_lds_bytes(S, kBlockBvh), st, S, q, hit, cnt,
-                           cap, blk_rays);
+        hipLaunchKernelGGL(k_intersect<true>, dim3(K), dim3(kBlockBvh),
+                           bvh_park_offset(S, kBlockBvh) + bvh_park_bytes(kBlockBvh), st, S, q, hit, cnt, cap, blk_rays);
     else
         hipLaunchKernelGGL(k_intersect<false>, dim3(K), dim3(kBlock), 0, st, S, q, hit, cnt, cap, blk_rays);
 }
