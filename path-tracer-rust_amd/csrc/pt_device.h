@@ -425,7 +425,24 @@ __device__ __forceinline__ void consider_object(const DevScene &S, const ObjPair
     }
     if (BVH && DEFER_WALK && ob.bvh_root[hf] != kNoBvh && S.n_bvh_nodes != 0u) {  // wave-uniform
         const float sq = f_sqrt(det);
-        if (!(det < 0.0f) && ((b - sq) >= eps || (b + sq) >= eps)) *want_walk = true;
+        bool pass = !(det < 0.0f) && ((b - sq) >= eps || (b + sq) >= eps);
+        // The first step of the walk, taken here with the root node in SGPRs: a ray that passes the (loose) sphere
+        // but misses both boxes of the root has nothing to find and is not parked.  best_t is the best of the objects
+        // visited so far, an upper bound of the bound the walk itself would use.
+        const int32_t root = ob.bvh_root[hf];
+        if (root >= 0 && __builtin_amdgcn_ballot_w64(pass) != 0ull) {
+            const BvhNode rn = ld_uniform(S.bvh_nodes + root);
+            const float big = 1e18f;
+            const vec3 inv = mk(__builtin_fmaxf(__builtin_fminf(1.0f / d.x, big), -big),
+                                __builtin_fmaxf(__builtin_fminf(1.0f / d.y, big), -big),
+                                __builtin_fmaxf(__builtin_fminf(1.0f / d.z, big), -big));
+            bool h0, h1;
+            f32x2 tin;
+            hit_boxes(rn, splat2(inv.x), splat2(inv.y), splat2(inv.z), splat2(o.x * inv.x), splat2(o.y * inv.y),
+                      splat2(o.z * inv.z), best_t, &h0, &h1, &tin);
+            pass = pass && (h0 || h1);
+        }
+        if (pass) *want_walk = true;
         return;
     }
     if (EXACT_GATES) {
