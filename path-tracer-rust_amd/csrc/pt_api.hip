@@ -553,6 +553,7 @@ int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uin
         c->scene.bvh_in_lds = (ref16 ? 2u : 0u) | (stage ? 1u : 0u);
     }
     c->scene.bvh_pair_base = fs.bvh_pair_base;
+    c->scene.leaf_quorum = getenv("PT_LEAF_QUORUM") ? (uint32_t)atoi(getenv("PT_LEAF_QUORUM")) : 12u;  // mesh.json: 65 (all) 11.7, 32 12.5, 16 12.8, 8 12.8, 1 11.0 G bounces/s
     c->scene.objs = c->d_objs.p;
     c->scene.obj_pairs = c->d_opairs.p;
     c->scene.tri_pairs = c->d_tris.p;

@@ -113,6 +113,7 @@ struct DevScene {
     uint32_t n_bvh_nodes;  // 0: no mesh of the scene has a BVH (or BVH use is switched off for this frame)
     uint32_t bvh_in_lds;   // bit 0: nodes are staged in LDS; bit 1: child references fit 16 bits (u16 traversal stacks)
     uint32_t bvh_pair_base;  // first TriPairRec that is a BVH leaf (leaf references on a u16 stack are relative to it)
+    uint32_t leaf_quorum;    // BVH walk: lanes on a leaf that send the wave to the triangle code (see bvh_closest)
 };
 
 // per-frame constants
@@ -334,32 +335,44 @@ __device__ __forceinline__ void bvh_closest(const DevScene &S, NodePtr nodes, Co
     for (;;) {
         // 1. walk down through inner nodes until this lane stands on a leaf (or has nothing left).  Lanes that
         //    arrive early wait here, so the (longer) triangle code below runs once per round for the whole wave.
-        while (cur >= 0) {
-            const BvhNode n = nodes[cur];
-            const float bound = __builtin_fminf(mt, best_t);
-            bool h0, h1;
-            f32x2 tin;
-            hit_boxes(n, ivx, ivy, ivz, oix, oiy, oiz, bound, &h0, &h1, &tin);
-            if (h0 && h1) {
-                const bool first0 = tin[0] <= tin[1];
-                if (sp < kBvhStack) stack[sp * stride] = codec.enc(first0 ? n.c[1] : n.c[0]);
-                ++sp;  // (the host guarantees tree depth < kBvhStack)
-                cur = first0 ? n.c[0] : n.c[1];
-            } else if (h0 || h1) {
-                cur = h0 ? n.c[0] : n.c[1];
-            } else if (sp != 0u) {
-                --sp;
-                cur = codec.dec(stack[sp * stride]);
-            } else {
-                cur = kDone;
+        for (;;) {  // wave-uniform loop: the lanes still on an inner node take one step per iteration
+            // leave for the triangle code when every lane stands on a leaf (or is done), or as soon as S.leaf_quorum
+            // lanes do: waiting for the deepest descent of 64 lanes leaves most of them idle, going at the first leaf
+            // runs the (twice as long) triangle code for one lane
+            if (__builtin_amdgcn_ballot_w64(cur >= 0) == 0ull) break;
+            if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(cur < 0 && cur != kDone)) >= S.leaf_quorum) break;
+            if (cur >= 0) {
+                const BvhNode n = nodes[cur];
+                const float bound = __builtin_fminf(mt, best_t);
+                bool h0, h1;
+                f32x2 tin;
+                hit_boxes(n, ivx, ivy, ivz, oix, oiy, oiz, bound, &h0, &h1, &tin);
+                if (h0 && h1) {
+                    const bool first0 = tin[0] <= tin[1];
+                    if (sp < kBvhStack) stack[sp * stride] = codec.enc(first0 ? n.c[1] : n.c[0]);
+                    ++sp;  // (the host guarantees tree depth < kBvhStack)
+                    cur = first0 ? n.c[0] : n.c[1];
+                } else if (h0 || h1) {
+                    cur = h0 ? n.c[0] : n.c[1];
+                } else if (sp != 0u) {
+                    --sp;
+                    cur = codec.dec(stack[sp * stride]);
+                } else {
+                    cur = kDone;
+                }
             }
         }
-        if (cur == kDone) break;
-        // 2. leaf: two triangles
-        test_pair<false>(S.tri_pairs[~cur], ox2, oy2, oz2, dx2, dy2, dz2, mt, mid);
-        if (sp == 0u) break;
-        --sp;
-        cur = codec.dec(stack[sp * stride]);
+        if (__builtin_amdgcn_ballot_w64(cur != kDone) == 0ull) break;  // every lane of the wave is done
+        // 2. leaf: two triangles (lanes still descending - early exit by quorum - and finished lanes sit out)
+        if (cur < 0 && cur != kDone) {
+            test_pair<false>(S.tri_pairs[~cur], ox2, oy2, oz2, dx2, dy2, dz2, mt, mid);
+            if (sp == 0u) {
+                cur = kDone;
+            } else {
+                --sp;
+                cur = codec.dec(stack[sp * stride]);
+            }
+        }
     }
 }
 
