@@ -16,7 +16,8 @@ The JSON line also carries
                 separate kernels and the figure is k_intersect's (24 B ray in + 8 B hit out per ray);
   cpu_baseline  the oracle (CPU port of the reference's rayon loop; the Rust reference cannot be built in
                 this image) timed on this box's host cores on a bounded sample of the same workload;
-  variants      the persistent megakernel backend and two concurrent pipelines on the same frame.
+  variants      the same frame through the persistent megakernel backend, through separate generate / intersect /
+                shade kernels (with that intersect kernel's own roofline) and through two concurrent pipelines.
 """
 import argparse
 import importlib
@@ -148,23 +149,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step(backend, profile, pipelines=1):
+    def step(backend, profile, pipelines=1, separate=False):
         ctx.set_profiling(profile)
         st = ctx.render(local.data_ptr(), W, H, spp, seed=args.seed, backend=backend, chunks=chunks,
-                        rays_per_pass=args.rays_per_pass, pipelines=pipelines)
+                        rays_per_pass=args.rays_per_pass, pipelines=pipelines, separate_kernels=separate)
         full = pkg.gather_chunks(local if dist_backend == "nccl" else local.cpu(), npix, rank, world, chunk, dist)
         return st, full
 
-    def timed(backend, steps, warmup, profile, pipelines=1):
+    def timed(backend, steps, warmup, profile, pipelines=1, separate=False):
         for _ in range(warmup):
-            step(backend, profile, pipelines)
+            step(backend, profile, pipelines, separate)
         barrier()
         t0 = time.perf_counter()
         bounces = isect_rays = samples = passes = 0
         isect_ms = 0.0
         launches = 0
         for _ in range(steps):
-            st, full = step(backend, profile, pipelines)
+            st, full = step(backend, profile, pipelines, separate)
             bounces += st.ray_bounces
             isect_rays += st.intersect_rays
             isect_ms += st.ms_intersect
@@ -270,6 +271,20 @@ def main():
         if args.backend == "wavefront" and args.pipelines == 1:
             # opt-in mode: 2 independent wavefront pipelines on 2 streams of this GPU (VALU-bound intersect of one
             # overlaps HBM-bound shade of another); not the headline because per-kernel timings lose their meaning
+            if main_run["launches"] == main_run["passes"]:
+                # the same frame with generate / intersect / shade as separate kernels per depth
+                # (PT_FLAG_SEPARATE_KERNELS), which has an intersect kernel of its own to put on the roofline:
+                # 24 B ray in + 8 B hit out per ray
+                vs = timed("wavefront", max(1, min(args.steps, 2)), 1, profile=True, separate=True)
+                ach = INTERSECT_BYTES_PER_RAY * vs["isect_rays"] / (vs["isect_ms"] * 1e-3) / 1e9
+                out["variants"]["wavefront_separate_kernels"] = {
+                    "value": vs["bounces"] / vs["dt"], "unit": "ray-bounces/s",
+                    "ms_per_step": 1e3 * vs["dt"] / max(1, min(args.steps, 2)),
+                    "image_identical_to_main_backend": bool(torch.equal(vs["image"], main_run["image"])),
+                    "roofline_k_intersect": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": ach / HBM_PEAK_GBS, "bytes_per_ray": INTERSECT_BYTES_PER_RAY,
+                                             "avg_launch_ms": vs["isect_ms"] / max(1, vs["launches"]),
+                                             "rays_per_s": vs["isect_rays"] / (vs["isect_ms"] * 1e-3)}}
             v3 = timed("wavefront", max(1, min(args.steps, 2)), 1, profile=False, pipelines=2)
             out["variants"]["wavefront_2_concurrent_pipelines"] = {
                 "value": v3["bounces"] / v3["dt"], "unit": "ray-bounces/s",

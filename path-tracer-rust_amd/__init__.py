@@ -50,6 +50,7 @@ class pt_stats(C.Structure):
 
 PT_OK, PT_ERR_INVALID, PT_ERR_NO_DEVICE, PT_ERR_HIP, PT_CANCELLED = 0, -1, -2, -3, -4
 BACKEND_WAVEFRONT, BACKEND_MEGAKERNEL = 0, 1
+PT_FLAG_NO_BVH, PT_FLAG_SEPARATE_KERNELS = 1, 2
 BACKENDS = {"wavefront": BACKEND_WAVEFRONT, "megakernel": BACKEND_MEGAKERNEL}
 
 _lib = None
@@ -139,11 +140,11 @@ class Context:
         _check(lib().pt_ctx_set_profiling(self._h, 1 if on else 0))
 
     def render(self, out_ptr, width, height, spp, seed=1, backend="wavefront", band=None, rays_per_pass=0,
-               stream=None, chunks=None, pipelines=1):
+               stream=None, chunks=None, pipelines=1, separate_kernels=False):
         """Render band [begin,end) (default whole frame) — or, with chunks=(chunk_pixels, first, step), this rank's
         interleaved chunks of it — into device memory at out_ptr (owned pixels * 3 floats)."""
         cfg = pt_config(width, height, spp, BACKENDS[backend], seed, 0, 0, rays_per_pass,
-                        ((pipelines & 15) << 8) if pipelines > 1 else 0)
+                        (((pipelines & 15) << 8) if pipelines > 1 else 0) | (PT_FLAG_SEPARATE_KERNELS if separate_kernels else 0))
         if band is not None:
             cfg.idx_begin, cfg.idx_end = band
         if chunks is not None:
