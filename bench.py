@@ -140,7 +140,7 @@ def main():
     # rank r renders image rows r, r+N, r+2N, ... (chunk = one row of framebuffer indices): contiguous eighths of
     # this image differ by up to 1.31x in ray bounces, interleaved rows by < 1 %
     chunk = W
-    counts, _ = pkg.chunk_owner_map(npix, world, chunk)
+    counts = pkg.chunk_counts(npix, world, chunk)
     chunks = (chunk, rank, world) if world > 1 else None
     local = torch.zeros((counts[rank], 3), dtype=torch.float32, device=dev)
 

@@ -174,6 +174,20 @@ def band_for_rank(npix, rank, world):
     return (npix * rank) // world, (npix * (rank + 1)) // world
 
 
+def chunk_counts(npix, world, chunk_pixels):
+    """Pixels owned by each rank under the interleaved partition (chunk c belongs to rank c % world), by arithmetic."""
+    n_chunks = (npix + chunk_pixels - 1) // chunk_pixels
+    last = npix - (n_chunks - 1) * chunk_pixels  # pixels of the last (possibly short) chunk
+    counts = []
+    for r in range(world):
+        mine = (n_chunks - r + world - 1) // world if n_chunks > r else 0
+        c = mine * chunk_pixels
+        if mine and (n_chunks - 1) % world == r:
+            c -= chunk_pixels - last
+        counts.append(c)
+    return counts
+
+
 def chunk_owner_map(npix, world, chunk_pixels):
     """Interleaved partition: chunk c (chunk_pixels consecutive framebuffer indices) belongs to rank c % world.
     Returns (counts, index) where counts[r] = pixels of rank r and index[r] = the framebuffer indices of rank r's
@@ -193,7 +207,7 @@ def gather_chunks(local, npix, rank, world, chunk_pixels, dist=None):
         return local
     if dist is None:
         import torch.distributed as dist
-    counts, index = chunk_owner_map(npix, world, chunk_pixels)
+    counts = chunk_counts(npix, world, chunk_pixels)  # (the index lists cost O(npix * world): only built if needed)
     assert local.shape[0] == counts[rank]
     if len(set(counts)) == 1 and npix % (world * chunk_pixels) == 0:
         flat = torch.empty((npix, 3), dtype=local.dtype, device=local.device)
@@ -201,6 +215,7 @@ def gather_chunks(local, npix, rank, world, chunk_pixels, dist=None):
         rounds = npix // (world * chunk_pixels)
         # flat is [rank][round][chunk_pixels]; the frame is [round][rank][chunk_pixels]
         return flat.view(world, rounds, chunk_pixels, 3).permute(1, 0, 2, 3).reshape(npix, 3)
+    _, index = chunk_owner_map(npix, world, chunk_pixels)
     m = max(counts)
     padded = torch.zeros((m, 3), dtype=local.dtype, device=local.device)
     padded[: local.shape[0]] = local

@@ -78,3 +78,16 @@ def test_band_partition_properties():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         pkg.band_for_rank(10, 3, 2)
+
+
+def test_chunk_counts_equal_the_owner_map():
+    """chunk_counts (arithmetic, used per frame) against chunk_owner_map (explicit index lists) on ragged cases."""
+    import random
+
+    rnd = random.Random(5)
+    cases = [(786432, 8, 1024), (786432, 3, 1024), (1, 1, 1), (5, 8, 2), (1000, 7, 33)]
+    cases += [(rnd.randint(1, 5000), rnd.randint(1, 9), rnd.randint(1, 300)) for _ in range(300)]
+    for npix, world, chunk in cases:
+        counts, index = pkg.chunk_owner_map(npix, world, chunk)
+        assert pkg.chunk_counts(npix, world, chunk) == counts
+        assert sum(counts) == npix and all(int(i.numel()) == c for i, c in zip(index, counts))
