@@ -4,6 +4,7 @@ Bars: geometry and control flow are bit-exact (hit distance/ids/points/normals, 
 radiance is summed top-down in 32.32 fixed point on the GPU and bottom-up in f32 by the reference, so the
 image is compared with the tolerance the north star states: 1e-4 per channel (observed ~1e-6)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -782,3 +783,50 @@ def test_random_scenes_against_oracle(gpu):
                 assert np.array_equal(out.view(np.uint32), ref_img.view(np.uint32)), (k, backend, flags)
         total += cnt.ray_bounces
     assert total > 100000
+
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("sid", ["single-sphere", "two-spheres", "three-spheres", "cartesian", "cornell", "mesh"])
+def test_gpu_against_golden_scene(gpu, sid):
+    """The committed golden vectors (tests/golden, tools/make_golden.py) without the oracle in the loop: the frame of
+    every device path within the tolerance and with exactly the recorded number of ray bounces; every recorded ray's
+    intersection - distance, object, triangle, hit point, normal - bit for bit."""
+    L, ctx = gpu
+    g = np.load(os.path.join(GOLDEN, "scene_%s.npz" % sid))
+    sc = ptlib.load_scene_py(ptlib.scene_path(sid))
+    w, h, spp, seed = int(g["width"]), int(g["height"]), int(g["spp"]), int(g["seed"])
+    for backend, flags in ((0, 0), (0, PT_FLAG_SEPARATE_KERNELS), (1, 0)):
+        cfg = PtConfig(w, h, spp, backend, seed, 0, 0, 0, flags)
+        out = np.zeros((w * h, 3), dtype=np.float32)
+        st = PtStats()
+        rc = L.pt_render(C.byref(cfg), C.byref(sc.cam), sc.objs, sc.n_objs, sc.tris, sc.n_tris, _np_f(out), None, None,
+                         None, C.byref(st))
+        assert rc == 0, L.pt_last_error()
+        assert st.ray_bounces == int(g["ray_bounces"]), (backend, flags)
+        assert float(np.abs(out - g["image"]).max()) <= TOL, (backend, flags)
+    set_scene(gpu, sc)
+    o, d = np.ascontiguousarray(g["ray_o"]), np.ascontiguousarray(g["ray_d"])
+    m = len(o)
+    t, oid, tid = np.zeros(m, np.float32), np.zeros(m, np.int32), np.zeros(m, np.int32)
+    x, nr = np.zeros((m, 3), np.float32), np.zeros((m, 3), np.float32)
+    rc = L.pt_ctx_intersect(ctx, _np_f(o), _np_f(d), m, _np_f(t), oid.ctypes.data_as(ptlib.i32p),
+                            tid.ctypes.data_as(ptlib.i32p), _np_f(x), _np_f(nr))
+    assert rc == 0, L.pt_last_error()
+    assert np.array_equal(oid, g["hit_object"]) and np.array_equal(tid, g["hit_triangle"])
+    for got, key in ((t, "hit_t"), (x, "hit_x"), (nr, "hit_n")):
+        assert np.array_equal(got.view(np.uint32), g[key].view(np.uint32)), key
+
+
+def test_gpu_against_golden_numerics(gpu):
+    L, ctx = gpu
+    g = np.load(os.path.join(GOLDEN, "numerics.npz"))
+    x = np.ascontiguousarray(g["sincos_x"])
+    n = len(x)
+    s, c, q, r = (np.zeros(n, np.float32) for _ in range(4))
+    ph = np.zeros(4 * n, np.uint32)
+    rc = L.pt_ctx_numerics_probe(ctx, _np_f(x), n, _np_f(s), _np_f(c), _np_f(q), _np_f(r), ph.ctypes.data_as(ptlib.u32p))
+    assert rc == 0, L.pt_last_error()
+    assert np.array_equal(s.view(np.uint32), g["sin"].view(np.uint32))
+    assert np.array_equal(c.view(np.uint32), g["cos"].view(np.uint32))

@@ -1,6 +1,7 @@
 """Pin the CPU restatement (oracle/) against every known-answer test the reference holds for the path:
 the 7 tests of src/render/test.rs, restated with the same inputs and the same exact expectations."""
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -179,3 +180,48 @@ def test_siphash13_kat():
     a = L.pto_siphash13(b"", 0)
     b = L.pto_siphash13(b"\0" * 8, 8)
     assert a != b and a == L.pto_siphash13(b"", 0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# committed golden vectors (tests/golden/*.npz, written by tools/make_golden.py)
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLDEN_SCENES = ["single-sphere", "two-spheres", "three-spheres", "cartesian", "cornell", "mesh"]
+
+
+@pytest.mark.parametrize("sid", GOLDEN_SCENES)
+def test_oracle_reproduces_golden_scene(sid):
+    """The oracle of today gives the committed frame, counters and per-ray intersections bit for bit (any thread
+    count): the fixtures pin the restatement against drift."""
+    g = np.load(os.path.join(GOLDEN, "scene_%s.npz" % sid))
+    O = ptlib.oracle()
+    sc = ptlib.load_scene_py(ptlib.scene_path(sid))
+    w, h, spp, seed = int(g["width"]), int(g["height"]), int(g["spp"]), int(g["seed"])
+    img, cnt, _ = ptlib.oracle_render(sc, w, h, spp, seed)
+    assert cnt.ray_bounces == int(g["ray_bounces"])
+    assert np.array_equal(img.view(np.uint32), g["image"].view(np.uint32))
+    o, d = np.ascontiguousarray(g["ray_o"]), np.ascontiguousarray(g["ray_d"])
+    m = len(o)
+    t, oid, tid = np.zeros(m, np.float32), np.zeros(m, np.int32), np.zeros(m, np.int32)
+    x, nr = np.zeros((m, 3), np.float32), np.zeros((m, 3), np.float32)
+    ps = sc.pto()
+    O.pto_intersect_batch(C.byref(ps), ptlib._np_f(o), ptlib._np_f(d), m, ptlib._np_f(t), oid.ctypes.data_as(ptlib.i32p),
+                          tid.ctypes.data_as(ptlib.i32p), ptlib._np_f(x), ptlib._np_f(nr))
+    assert np.array_equal(oid, g["hit_object"]) and np.array_equal(tid, g["hit_triangle"])
+    for got, key in ((t, "hit_t"), (x, "hit_x"), (nr, "hit_n")):
+        assert np.array_equal(got.view(np.uint32), g[key].view(np.uint32)), key
+
+
+def test_oracle_reproduces_golden_numerics():
+    g = np.load(os.path.join(GOLDEN, "numerics.npz"))
+    O = ptlib.oracle()
+    s = np.array([O.pto_sinf(float(v)) for v in g["sincos_x"]], np.float32)
+    c = np.array([O.pto_cosf(float(v)) for v in g["sincos_x"]], np.float32)
+    assert np.array_equal(s.view(np.uint32), g["sin"].view(np.uint32))
+    assert np.array_equal(c.view(np.uint32), g["cos"].view(np.uint32))
+    out = np.zeros(4, np.uint32)
+    for ctr, key, want in zip(g["philox_ctr"], g["philox_key"], g["philox_out"]):
+        ctr, key = np.ascontiguousarray(ctr), np.ascontiguousarray(key)
+        O.pto_philox4x32_10(ctr.ctypes.data_as(ptlib.u32p), key.ctypes.data_as(ptlib.u32p), out.ctypes.data_as(ptlib.u32p))
+        assert np.array_equal(out, want)
+    gi = np.array([O.pto_to_int_with_gamma_correction(float(v)) for v in g["gamma_x"]], np.uint32)
+    assert np.array_equal(gi, g["gamma_int"])
