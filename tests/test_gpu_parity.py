@@ -830,3 +830,53 @@ def test_gpu_against_golden_numerics(gpu):
     assert rc == 0, L.pt_last_error()
     assert np.array_equal(s.view(np.uint32), g["sin"].view(np.uint32))
     assert np.array_equal(c.view(np.uint32), g["cos"].view(np.uint32))
+
+
+REF_SPHERE_KATS = [  # src/render/test.rs:43-144, the reference's own intersect_scene fixtures
+    ((0, 0, -3), (0, 0, 0), (0, 0, -1), (0, 2.0, [0, 0, -2], [0, 0, 1])),
+    ((0, 0, -3), (2, 0, 0), "norm(1,0,-1)", None),
+    ((0, 0, 0), (0, 0, 0), (0, 0, -1), (0, 1.0, [0, 0, -1], [0, 0, -1])),
+    ((0, 0, -3), (0, 1, 0), (0, 0, -1), (0, 3.0, [0, 1, -3], [0, 1, 0])),
+]
+
+
+@pytest.mark.parametrize("pos,o,d,want", REF_SPHERE_KATS)
+def test_reference_sphere_kats_through_the_c_abi(gpu, pos, o, d, want):
+    """The reference's own intersect_scene fixtures (src/render/test.rs:43-144) against the HIP path, exact values."""
+    L, ctx = gpu
+    if isinstance(d, str):
+        v = np.array([1.0, 0.0, -1.0], np.float32)
+        inv = np.float32(1.0) / np.sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2], dtype=np.float32)
+        d = [float(c) for c in v * inv]  # glam normalize: v * (1 / length)
+    sc = ptlib.Scene("kat", ptlib.make_camera((0, 0, 5), (0, 0, -1)),
+                     [ptlib.make_sphere(pos, 1.0, (1, 1, 1), (0, 0, 0), "Diffuse")], [])
+    set_scene(gpu, sc)
+    oa = np.array([o], np.float32)
+    da = np.array([d], np.float32)
+    t, oid, tid = np.zeros(1, np.float32), np.zeros(1, np.int32), np.zeros(1, np.int32)
+    x, nr = np.zeros((1, 3), np.float32), np.zeros((1, 3), np.float32)
+    rc = L.pt_ctx_intersect(ctx, _np_f(oa), _np_f(da), 1, _np_f(t), oid.ctypes.data_as(ptlib.i32p),
+                            tid.ctypes.data_as(ptlib.i32p), _np_f(x), _np_f(nr))
+    assert rc == 0, L.pt_last_error()
+    if want is None:
+        assert int(oid[0]) == -1
+    else:
+        assert (int(oid[0]), float(t[0]), list(x[0]), list(nr[0])) == \
+               (want[0], want[1], [float(v) for v in want[2]], [float(v) for v in want[3]])
+
+
+def test_reference_radiance_test_through_the_c_abi(gpu):
+    """src/render/test.rs:146-183 (`test_radiance`): a red diffuse unit sphere in front, an emissive one behind the
+    camera; the reference asserts mean radiance .x > 0.3 over 10 000 samples of the central ray (analytic 50/144).
+    Here: the central pixel of a 1001x667 frame (its rays leave the lens centre within 0.03 degrees of -z), 65 536
+    samples, on every device path."""
+    cam = ptlib.make_camera((0, 0, 0.035), (0, 0, -1))  # lens centre at the origin, looking down -z
+    sc = ptlib.Scene("t", cam, [ptlib.make_sphere((0, 0, -3), 1.0, (1, 0, 0), (0, 0, 0), "Diffuse"),
+                                ptlib.make_sphere((0, 0, 10), 1.0, (0, 0, 0), (50, 50, 50), "Diffuse")], [])
+    w, h = 1001, 667
+    idx = (h - 1 - h // 2) * w + w // 2
+    for backend in (0, 1):
+        got, st = gpu_render(gpu, sc, w, h, 65536, 3, backend, band=(idx, idx + 1))
+        px = got[idx]
+        assert px[0] > 0.3 and abs(px[0] - 50.0 / 144.0) < 0.02, px
+        assert px[1] == 0.0 and px[2] == 0.0
