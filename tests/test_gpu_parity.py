@@ -760,9 +760,9 @@ def test_random_scenes_against_oracle(gpu):
     """40 random scenes through every device path (k_pass, separate kernels, megakernel, with and without the
     acceleration structures): bounce counts equal the oracle's exactly, images within the tolerance, and the device
     paths agree with each other bit for bit."""
-    rng = np.random.default_rng(2026)
+    rng = np.random.default_rng(int(os.environ.get("PT_FUZZ_SEED", "2026")))
     total = 0
-    for k in range(40):
+    for k in range(int(os.environ.get("PT_FUZZ_SCENES", "40"))):  # one-off long runs: PT_FUZZ_SCENES=500 PT_FUZZ_SEED=...
         sc = _random_scene(rng, k)
         w, h, spp = 40, 28, 6
         want, cnt, _ = ptlib.oracle_render(sc, w, h, spp, 100 + k)
