@@ -543,6 +543,7 @@ int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uin
     c->n_bvh_nodes = (uint32_t)fs.bvh_nodes.size();
     c->scene.bvh_nodes = c->d_nodes.p;
     c->scene.n_bvh_nodes = c->n_bvh_nodes;
+    c->scene.planar = 1u;
     {
         // bit 1: node and leaf references fit 16 bits (u16 traversal stacks); bit 0: nodes staged in LDS by every
         // workgroup.  With the walks done in dense waves (k_intersect<true>) occupancy is worth more than LDS-resident
@@ -706,8 +707,10 @@ int pt_ctx_render(pt_ctx *c, const pt_config *cfg, void *d_out_rgb, void *hip_st
         if (stats) memset(stats, 0, sizeof *stats);
         const double t0p = now_ms();
         c->scene.n_bvh_nodes = (cfg->flags & PT_FLAG_NO_BVH) ? 0u : c->n_bvh_nodes;
+        c->scene.planar = (cfg->flags & PT_FLAG_NO_BVH) ? 0u : 1u;
         rc = render_pipelined(c, cfg, n_pipes, ib, ie, (float *)d_out_rgb, cancel, cb, user, stats);
         c->scene.n_bvh_nodes = c->n_bvh_nodes;
+    c->scene.planar = 1u;
         if (stats) stats->ms_total = now_ms() - t0p;
         return rc;
     }
@@ -720,6 +723,7 @@ int pt_ctx_render(pt_ctx *c, const pt_config *cfg, void *d_out_rgb, void *hip_st
     c->live_stream = st;
     // PT_FLAG_NO_BVH: scan meshes triangle by triangle as the reference does (same result, for A/B checks)
     c->scene.n_bvh_nodes = (cfg->flags & PT_FLAG_NO_BVH) ? 0u : c->n_bvh_nodes;
+    c->scene.planar = (cfg->flags & PT_FLAG_NO_BVH) ? 0u : 1u;
     const double t0 = now_ms();
     if (cfg->backend == PT_BACKEND_WAVEFRONT)
         rc = render_wavefront(c, cfg, F, st, cancel, cb, user, stats);
@@ -734,6 +738,7 @@ int pt_ctx_render(pt_ctx *c, const pt_config *cfg, void *d_out_rgb, void *hip_st
     }
     if (stats) stats->ms_total = now_ms() - t0;
     c->scene.n_bvh_nodes = c->n_bvh_nodes;
+    c->scene.planar = 1u;
     c->live_npix = 0;
     return rc;
 }

@@ -52,8 +52,10 @@ struct alignas(16) ObjPairRec {
     uint32_t pair_count[2];
     int32_t bvh_root[2];
     uint32_t obj[2];            // object index
-    uint32_t admit[2];          // mesh whose bounding sphere is so large that a wave of rays practically never misses
-                                // it as a whole: the speculative scan skips the gate arithmetic (see scan_scene)
+    uint32_t admit[2];          // bit 0: mesh whose bounding sphere is so large that a wave of rays practically never misses
+                                // it as a whole: the speculative scan skips the gate arithmetic (see scan_scene);
+                                // bits 1-2: 1 + the axis both edge vectors of every triangle of the mesh are exactly
+                                // zero along (a mesh in an axis-aligned plane: test_pair_planar), 0 = none
 };
 
 // Two consecutive triangles of one mesh (world space), component by component, read with a wave-uniform
@@ -114,6 +116,7 @@ struct DevScene {
     uint32_t bvh_in_lds;   // bit 0: nodes are staged in LDS; bit 1: child references fit 16 bits (u16 traversal stacks)
     uint32_t bvh_pair_base;  // first TriPairRec that is a BVH leaf (leaf references on a u16 stack are relative to it)
     uint32_t leaf_quorum;    // BVH walk: lanes on a leaf that send the wave to the triangle code (see bvh_closest)
+    uint32_t planar;         // 0: every triangle through the general test_pair (PT_FLAG_NO_BVH)
 };
 
 // per-frame constants
@@ -259,6 +262,51 @@ __device__ __forceinline__ void test_pair(const TriPairRec &tr, f32x2 ox2, f32x2
         // determinant == 0, which the first condition already rejects - so plain ordered compares are exact here.
         // `u > 1.0` (mod.rs:579) needs no instruction of its own: with v >= 0, u <= RN(u+v) by monotonicity of
         // rounding, so u > 1 implies (u+v) > 1, which is tested.
+        const bool keep = (f_abs(determinant[hf]) >= 1e-4f) & (u[hf] >= 0.0f) & (v[hf] >= 0.0f) & (uv[hf] <= 1.0f) &
+                          (dist[hf] > 0.0f);
+        const int32_t id = (int32_t)tr.id[hf];
+        const bool closer = ORDERED ? (dist[hf] < mt) : (dist[hf] < mt || (dist[hf] == mt && id < mid));
+        if (keep & closer) {
+            mt = dist[hf];
+            mid = id;
+        }
+    }
+}
+
+// test_pair for two triangles that lie in a plane perpendicular to axis AXIS: both edge vectors are exactly zero along
+// it (the walls of the reference's rooms, scenes.rs:322-367).  The reference's arithmetic then multiplies by those
+// zeros and adds the +-0 products; leaving them out gives the same numbers - x*0 = +-0, y + (+-0) = y for y != 0 - except
+// that a result which is itself zero may come out with the other sign, and no decision of mod.rs:571-594 and no
+// output depends on the sign of a zero (|det| < 1e-4, u < 0, v < 0, u + v > 1, t <= 0 treat -0 as +0; a hit has
+// t != 0).  12 of the 53 packed instructions go.  With (i, j, k) = (AXIS, AXIS+1, AXIS+2) mod 3:
+//   p = d x e2:  p_i = d_j e2_k - e2_j d_k,   p_j = -(e2_k d_i),   p_k = d_i e2_j          (mod.rs:563)
+//   det = e1_j p_j + e1_k p_k   (the two products the reference adds to a +-0, in either order)   (mod.rs:564)
+//   q = tv x e1: q_i = tv_j e1_k - e1_j tv_k, q_j = -(e1_k tv_i),  q_k = tv_i e1_j          (mod.rs:583)
+//   t = (e2_j q_j + e2_k q_k) / det                                                        (mod.rs:589)
+// u and v keep the reference's three-term sums in x, y, z order.
+template <int AXIS, bool ORDERED>
+__device__ __forceinline__ void test_pair_planar(const TriPairRec &tr, f32x2 ox2, f32x2 oy2, f32x2 oz2, f32x2 dx2,
+                                                 f32x2 dy2, f32x2 dz2, float &mt, int32_t &mid) {
+    constexpr int I = AXIS, J = (AXIS + 1) % 3, K = (AXIS + 2) % 3;
+    const f32x2 e1[3] = {ld2(tr.e1x), ld2(tr.e1y), ld2(tr.e1z)};
+    const f32x2 e2[3] = {ld2(tr.e2x), ld2(tr.e2y), ld2(tr.e2z)};
+    const f32x2 dd[3] = {dx2, dy2, dz2};
+    f32x2 p[3], q[3];
+    p[I] = dd[J] * e2[K] - e2[J] * dd[K];
+    p[J] = -(e2[K] * dd[I]);
+    p[K] = dd[I] * e2[J];
+    const f32x2 determinant = e1[J] * p[J] + e1[K] * p[K];
+    const f32x2 inv_det = f_rcp2(determinant);
+    const f32x2 tv[3] = {ox2 - ld2(tr.ax), oy2 - ld2(tr.ay), oz2 - ld2(tr.az)};
+    const f32x2 u = ((tv[0] * p[0] + tv[1] * p[1]) + tv[2] * p[2]) * inv_det;
+    q[I] = tv[J] * e1[K] - e1[J] * tv[K];
+    q[J] = -(e1[K] * tv[I]);
+    q[K] = tv[I] * e1[J];
+    const f32x2 v = ((dx2 * q[0] + dy2 * q[1]) + dz2 * q[2]) * inv_det;
+    const f32x2 dist = (e2[J] * q[J] + e2[K] * q[K]) * inv_det;
+    const f32x2 uv = u + v;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
         const bool keep = (f_abs(determinant[hf]) >= 1e-4f) & (u[hf] >= 0.0f) & (v[hf] >= 0.0f) & (uv[hf] <= 1.0f) &
                           (dist[hf] > 0.0f);
         const int32_t id = (int32_t)tr.id[hf];
@@ -477,7 +525,18 @@ __device__ __forceinline__ void consider_object(const DevScene &S, const ObjPair
         const f32x2 ox2 = splat2(o.x), oy2 = splat2(o.y), oz2 = splat2(o.z);
         const f32x2 dx2 = splat2(d.x), dy2 = splat2(d.y), dz2 = splat2(d.z);
         const uint32_t pb = ob.pair_begin[hf], pc = ob.pair_count[hf];
-        if (root == kNoBvh) {
+        const uint32_t plane = S.planar ? (ob.admit[hf] >> 1) & 3u : 0u;  // wave-uniform
+        if (root == kNoBvh && plane != 0u) {
+            for (uint32_t p = 0; p < pc; ++p) {
+                const TriPairRec tr = ld_uniform(S.tri_pairs + (pb + p));
+                if (plane == 1u)
+                    test_pair_planar<0, true>(tr, ox2, oy2, oz2, dx2, dy2, dz2, mt, mid);
+                else if (plane == 2u)
+                    test_pair_planar<1, true>(tr, ox2, oy2, oz2, dx2, dy2, dz2, mt, mid);
+                else
+                    test_pair_planar<2, true>(tr, ox2, oy2, oz2, dx2, dy2, dz2, mt, mid);
+            }
+        } else if (root == kNoBvh) {
             for (uint32_t p = 0; p < pc; ++p)  // wave-uniform index -> scalar loads
                 test_pair<true>(ld_uniform(S.tri_pairs + (pb + p)), ox2, oy2, oz2, dx2, dy2, dz2, mt, mid);
         } else {  // BVH switched off for this frame: the reference's full scan over BVH-ordered records
@@ -507,7 +566,7 @@ __device__ __forceinline__ HitRec scan_scene(const DevScene &S, vec3 o, vec3 d, 
         // Speculative pass: a mesh flagged `admit` goes straight to its triangles.  Admitting more meshes than the
         // reference keeps the argument of intersect_scene_dev intact (winner over a superset, verified afterwards);
         // what it saves is the gate arithmetic of spheres that no wave ever misses (the walls of a room).
-        const bool a0 = !EXACT_GATES && ob.admit[0] != 0u, a1 = !EXACT_GATES && ob.admit[1] != 0u;
+        const bool a0 = !EXACT_GATES && (ob.admit[0] & 1u) != 0u, a1 = !EXACT_GATES && (ob.admit[1] & 1u) != 0u;
         if (a0 && a1) {  // wave-uniform
             consider_object<BVH, EXACT_GATES, DEFER_WALK>(S, ob, 0, 0.0f, 0.0f, o, d, lds, best_t, best_id, true, want_walk);
             consider_object<BVH, EXACT_GATES, DEFER_WALK>(S, ob, 1, 0.0f, 0.0f, o, d, lds, best_t, best_id, true, want_walk);

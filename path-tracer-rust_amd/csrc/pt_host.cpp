@@ -367,6 +367,22 @@ bool flatten_scene(const pt_camera &cam, const pt_object *objs, uint32_t n_objs,
             // scene.  Spheres above an eighth of the scene diagonal are not worth their arithmetic.
             // (a mesh with a BVH keeps its gate: there it saves a whole walk, and the deferred walks need its result)
             pr.admit[hf] = (r.kind == kKindMesh && r.bvh_root == kNoBvh && r.rr > (scene_R * 0.125f) * (scene_R * 0.125f)) ? 1u : 0u;
+            // a mesh scanned pair by pair whose triangles all lie in one axis-aligned plane: which axis (bits 1-2)
+            if (r.kind == kKindMesh && r.bvh_root == kNoBvh) {
+                for (uint32_t ax = 0; ax < 3; ++ax) {
+                    bool flat = r.pair_count != 0u;
+                    for (uint32_t pp = r.pair_begin; flat && pp < r.pair_begin + r.pair_count; ++pp) {
+                        const TriPairRec &tp = out.tri_pairs[pp];
+                        const float *e1 = ax == 0 ? tp.e1x : (ax == 1 ? tp.e1y : tp.e1z);
+                        const float *e2 = ax == 0 ? tp.e2x : (ax == 1 ? tp.e2y : tp.e2z);
+                        flat = e1[0] == 0.0f && e1[1] == 0.0f && e2[0] == 0.0f && e2[1] == 0.0f;  // fillers are all zero
+                    }
+                    if (flat) {
+                        pr.admit[hf] |= (ax + 1u) << 1;
+                        break;
+                    }
+                }
+            }
         } else {  // filler: a sphere whose discriminant is -inf for every finite ray
             pr.cx[hf] = pr.cy[hf] = pr.cz[hf] = 0.0f;
             pr.rr[hf] = -std::numeric_limits<float>::infinity();
