@@ -12,8 +12,8 @@ The JSON line also carries
                 against the 8 TB/s HBM peak.  Scenes without BVH meshes (the default) run a whole pass per launch
                 (k_pass): its algorithmic traffic is the ray queue - every ray of depth >= 1 is written once and
                 read once, 40 B each way (origin, direction, throughput, bookkeeping word); primary rays are made in
-                registers and hit records never leave them.  Scenes with a BVH run generate / intersect / shade as
-                separate kernels and the figure is k_intersect's (24 B ray in + 8 B hit out per ray);
+                registers and hit records never leave them (k_pass_bvh, scenes with a BVH: the primaries go through the
+                queue too).  With PT_FLAG_SEPARATE_KERNELS the figure is k_intersect's (24 B ray in + 8 B hit out);
   cpu_baseline  the oracle (CPU port of the reference's rayon loop; the Rust reference cannot be built in
                 this image) timed on this box's host cores on a bounded sample of the same workload;
   variants      the same frame through the persistent megakernel backend, through separate generate / intersect /
@@ -216,9 +216,11 @@ def main():
         # rank 0's launches of the dominant kernel (every rank runs the same kernel on its own rows)
         one_kernel = main_run["launches"] == main_run["passes"]  # one launch per pass: k_pass
         rays, ms, launches = main_run["isect_rays"], main_run["isect_ms"], max(1, main_run["launches"])
+        has_bvh = any(scene.objects[i].kind == 1 and scene.objects[i].tri_count >= 16 for i in range(scene.n_objects))
         if one_kernel:
-            kernel = "k_pass"
-            stored = rays - main_run["samples"]  # rays of depth >= 1
+            kernel = "k_pass_bvh" if has_bvh else "k_pass"
+            # k_pass makes the primary rays in registers; k_pass_bvh sends them through the queue like every level
+            stored = rays if has_bvh else rays - main_run["samples"]
             alg_bytes = QUEUE_BYTES_PER_STORED_RAY * stored
             per_unit = {"bytes_per_stored_ray": QUEUE_BYTES_PER_STORED_RAY, "stored_rays_per_launch": stored / launches,
                         "bytes_per_ray_bounce": alg_bytes / rays}

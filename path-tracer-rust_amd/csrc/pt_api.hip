@@ -254,7 +254,10 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
     const int n_depth = kMaxDepth;  // rays of depth 0..11 exist
     // scenes without BVH meshes run a pass as one launch; PT_PASS_KERNEL=0 keeps the three-kernel form (A/B, profiling)
     static const bool pass_kernel_off = getenv("PT_PASS_KERNEL") && atoi(getenv("PT_PASS_KERNEL")) == 0;
-    const bool one_kernel = c->scene.n_bvh_nodes == 0u && !pass_kernel_off && !(cfg->flags & PT_FLAG_SEPARATE_KERNELS);
+    // (BVH scenes: k_pass_bvh, unless the nodes are staged in LDS - PT_BVH_LDS=1 - or PT_PASS_BVH=0)
+    static const bool pass_bvh_off = getenv("PT_PASS_BVH") && atoi(getenv("PT_PASS_BVH")) == 0;
+    const bool bvh_ok = c->scene.n_bvh_nodes == 0u || (!(c->scene.bvh_in_lds & 1u) && !pass_bvh_off);
+    const bool one_kernel = bvh_ok && !pass_kernel_off && !(cfg->flags & PT_FLAG_SEPARATE_KERNELS);
     size_t ev_i = 0;
     hipEvent_t ev_begin = get_event(c, ev_i++), ev_end = get_event(c, ev_i++);
     hipEvent_t pass_done[2] = {get_event(c, ev_i++), get_event(c, ev_i++)};
@@ -287,8 +290,12 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
                 }
                 HIP_TRY(hipEventRecord(a, st));
             }
-            launch_pass(st, K, c->scene, F, queue_of(c, 0), queue_of(c, 1), cap, s0, s_here, m, c->acc.p, c->blk_rays.p,
-                        c->flags.p);
+            if (c->scene.n_bvh_nodes != 0u)
+                launch_pass_bvh(st, K, c->scene, F, queue_of(c, 0), queue_of(c, 1), cap, s0, s_here, m, c->acc.p,
+                                c->blk_rays.p, c->flags.p);
+            else
+                launch_pass(st, K, c->scene, F, queue_of(c, 0), queue_of(c, 1), cap, s0, s_here, m, c->acc.p,
+                            c->blk_rays.p, c->flags.p);
             if (c->profiling) {
                 HIP_TRY(hipEventRecord(b, st));
                 ++n_prof;

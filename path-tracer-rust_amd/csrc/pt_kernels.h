@@ -23,6 +23,10 @@ struct RayQueue {
 void launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const FrameParams &F, const RayQueue &q0,
                  const RayQueue &q1, uint32_t cap, uint32_t s0, uint32_t s_here, uint32_t m, unsigned long long *acc,
                  unsigned long long *blk_rays, uint32_t *flags);
+// the same for scenes with BVH meshes (nodes read from global memory: DevScene.bvh_in_lds bit 0 clear)
+void launch_pass_bvh(hipStream_t st, uint32_t K, const DevScene &S, const FrameParams &F, const RayQueue &q0,
+                     const RayQueue &q1, uint32_t cap, uint32_t s0, uint32_t s_here, uint32_t m, unsigned long long *acc,
+                     unsigned long long *blk_rays, uint32_t *flags);
 void launch_generate(hipStream_t st, uint32_t K, const FrameParams &F, const RayQueue &q, uint32_t *cnt0,
                      uint32_t cap, uint32_t s0, uint32_t s_here, uint32_t m);
 void launch_intersect(hipStream_t st, uint32_t K, const DevScene &S, const RayQueue &q, float2 *hit,

@@ -5,7 +5,8 @@
 //                                      (render_pixel, mod.rs:812-843), then level by level closest hit
 //                                      (intersect_scene, mod.rs:631-659), roulette / emission / BRDF sample / refract
 //                                      split (radiance body, mod.rs:665-789) and stream compaction
-// scenes with a BVH (and PT_PASS_KERNEL=0): the same steps as separate kernels
+//   k_pass_bvh                         the same for scenes with BVH meshes (walks parked per wave, done 64 at a time)
+// PT_FLAG_SEPARATE_KERNELS / PT_PASS_KERNEL=0: the same steps as separate kernels
 //   k_generate; for depth = 0..11: k_intersect, k_shade
 //   k_resolve (once per frame)         /spp, clamp                      (mod.rs:849-856)
 //
@@ -463,6 +464,180 @@ __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, R
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_pass for scenes with a BVH: the same one-launch-per-pass walk of a stream, with the BVH walks of k_intersect<true>:
+// the scan skips them (gates exact, first step of the walk taken from SGPRs), a ray that needs one is parked per wave
+// in LDS as (ray index, best hit so far) - the ray itself stays in the queue slice - and walked, shaded and appended
+// 64 at a time.  Level 0 goes through the queue too, so that every parked ray can be read back by index.
+constexpr uint32_t kPassParkCap = 128;  // 63 left over + 64 new at most
+__host__ __device__ inline size_t pass_bvh_stack_offset(uint32_t m) { return pass_lds_defer_offset(m); }
+__host__ __device__ inline size_t pass_bvh_park_offset(const DevScene &S, uint32_t m) {
+    return (pass_bvh_stack_offset(m) + (size_t)kBvhStack * kBlock * ((S.bvh_in_lds & 2u) ? sizeof(uint16_t) : sizeof(uint32_t)) + 15) &
+           ~(size_t)15;
+}
+__host__ __device__ inline size_t pass_bvh_lds_bytes(const DevScene &S, uint32_t m) {
+    return pass_bvh_park_offset(S, m) + (size_t)(kBlock / 64u) * kPassParkCap * 12u;
+}
+
+__global__ __launch_bounds__(kBlock, 5) void k_pass_bvh(DevScene S, FrameParams F, RayQueue q0, RayQueue q1, uint32_t cap,
+                                                        uint32_t s0, uint32_t s_here, uint32_t m,
+                                                        unsigned long long *__restrict__ acc,
+                                                        unsigned long long *__restrict__ blk_rays,
+                                                        uint32_t *__restrict__ flags) {
+    unsigned long long *lds_acc = reinterpret_cast<unsigned long long *>(dyn_lds);
+    uint32_t *s_tail_p = reinterpret_cast<uint32_t *>(lds_acc + 3u * m);
+    const uint32_t b = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t mb = stream_pixel_count(F.npix, F.n_streams, b);  // <= m
+    if (mb == 0u) return;
+    for (uint32_t k = tid; k < 3u * m; k += kBlock) lds_acc[k] = 0ull;
+    if (tid == 0) s_tail_p[0] = s_tail_p[1] = 0u;
+    uint32_t *lds_pix = s_tail_p + 4;
+    for (uint32_t j = tid; j < mb; j += kBlock) lds_pix[j] = global_pixel(F, stream_pixel(F.n_streams, b, j));
+    // traversal stacks (one column per thread), then this wave's parking area: u32 ray index | f32 t | i32 id
+    uint4 *const stacks = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(dyn_lds) + pass_bvh_stack_offset(m));
+    char *park = reinterpret_cast<char *>(dyn_lds) + pass_bvh_park_offset(S, m) + (size_t)(tid >> 6) * kPassParkCap * 12u;
+    uint32_t *const p_idx = reinterpret_cast<uint32_t *>(park);
+    float *const p_t = reinterpret_cast<float *>(p_idx + kPassParkCap);
+    int32_t *const p_id = reinterpret_cast<int32_t *>(p_t + kPassParkCap);
+    const size_t base = (size_t)b * cap;
+    ShadeParams P;
+    P.idx_begin = F.idx_begin;
+    P.npix = F.npix;
+    P.n_streams = F.n_streams;
+    P.seed_lo = F.seed_lo;
+    P.seed_hi = F.seed_hi;
+    P.debug = F.debug;
+    P.s0 = s0;
+    P.chunk_pixels = F.chunk_pixels;
+    P.chunk_first = F.chunk_first;
+    P.chunk_step = F.chunk_step;
+    bool overflow = false;
+    unsigned long long total = 0ull;
+    uint32_t n = mb * s_here;  // rays of the current level
+    __syncthreads();           // lds_pix
+    for (uint32_t g = tid; g < n; g += kBlock) {  // level 0: render_pixel's rays (pixel g % mb, sample s0 + g / mb)
+        const uint32_t pj = g % mb, sj = g / mb;
+        const PathRay r = primary_ray(F, lds_pix[pj], s0 + sj);
+        store_ray(q0, base + g, r.o, r.d, r.thr, pack_word(pj, sj, 0u, 1u));
+    }
+    uint32_t n_park = 0;  // wave-uniform
+    StreamSlice qin{}, qout{};
+    uint32_t *tail_p = nullptr;
+    auto append = [&](const ShadeOut &so, uint32_t word) {
+        const uint64_t m1 = __builtin_amdgcn_ballot_w64(so.n_rays >= 1);
+        const uint64_t m2 = __builtin_amdgcn_ballot_w64(so.n_rays == 2);
+        const uint32_t c1 = (uint32_t)__builtin_popcountll(m1), c2 = (uint32_t)__builtin_popcountll(m2);
+        if ((c1 + c2) == 0u) return;  // wave-uniform
+        uint32_t wbase = 0;
+        if (lane == 0u) wbase = atomicAdd(tail_p, c1 + c2);
+        wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+        if (so.n_rays >= 1) {
+            const uint32_t slot = wbase + lane_prefix(m1);
+            if (slot < cap)
+                store_ray(qout, slot, so.x, so.d0, so.thr0,
+                          pack_word(word_pix(word), word_sample(word), meta_depth(so.meta0), meta_branch(so.meta0)));
+            else
+                overflow = true;
+        }
+        if (so.n_rays == 2) {
+            const uint32_t slot = wbase + c1 + lane_prefix(m2);
+            if (slot < cap)
+                store_ray(qout, slot, so.x, so.d1, so.thr1,
+                          pack_word(word_pix(word), word_sample(word), meta_depth(so.meta1), meta_branch(so.meta1)));
+            else
+                overflow = true;
+        }
+    };
+    auto load_ray = [&](uint32_t i, PathRay &in, uint32_t &word) {
+        const float4 a = *reinterpret_cast<const float4 *>(qin.od0 + i * 16u);
+        const float4 tp = *reinterpret_cast<const float4 *>(qin.tp + i * 16u);
+        const float2 c = *reinterpret_cast<const float2 *>(qin.od1 + i * 8u);
+        in.o = mk(a.x, a.y, a.z);
+        in.d = mk(a.w, c.x, c.y);
+        in.thr = mk(tp.x, tp.y, tp.z);
+        word = __float_as_uint(tp.w);
+    };
+    auto shade_and_append = [&](bool valid, PathRay &in, uint32_t word, HitRec h) {
+        ShadeOut so;
+        so.n_rays = 0;
+        so.emits = false;
+        if (valid && h.id >= 0) {
+            in.pix = lds_pix[word_pix(word)];
+            in.meta = pack_meta(s0 + word_sample(word), word_depth(word), word_branch(word));
+            shade_hit(S, P, in, h, so);
+            if (so.emits) add_radiance_lds(lds_acc, m, word_pix(word), so.contrib);
+        }
+        append(so, word);
+    };
+    // 64 parked rays (or the rest): walk, shade, append
+    auto walk_batch = [&](uint32_t e, bool valid) {
+        PathRay in;
+        uint32_t word = 0;
+        HitRec h;
+        h.t = 0.0f;
+        h.id = -1;
+        if (valid) {
+            load_ray(p_idx[e], in, word);
+            h.t = p_t[e];
+            h.id = p_id[e];
+            if (walk_deferred(S, in.o, in.d, stacks, h.t, h.id)) h = scan_scene<true, true>(S, in.o, in.d, stacks);
+        }
+        shade_and_append(valid, in, word, h);
+    };
+    for (uint32_t depth = 0; depth < (uint32_t)kMaxDepth && n != 0u; ++depth) {
+        qin = slice_of((depth & 1u) ? q1 : q0, base);
+        qout = slice_of((depth & 1u) ? q0 : q1, base);
+        __syncthreads();  // level `depth` of the stream is complete and visible to the whole workgroup
+        if (tid == 0) s_tail_p[(depth + 1u) & 1u] = 0u;  // two-counter protocol of k_pass
+        tail_p = s_tail_p + (depth & 1u);
+        total += n;
+        for (uint32_t j0 = 0; j0 < n; j0 += kBlock) {  // uniform trip count: every lane reaches the ballots
+            const uint32_t i = j0 + tid;
+            PathRay in;
+            uint32_t word = 0;
+            HitRec h;
+            h.t = 0.0f;
+            h.id = -1;
+            bool want = false;
+            if (i < n) {
+                load_ray(i, in, word);
+                h = intersect_scene_dev<true, true>(S, in.o, in.d, stacks, &want);
+            }
+            shade_and_append(i < n && !want, in, word, h);
+            const uint64_t mw = __builtin_amdgcn_ballot_w64(want);
+            if (mw != 0ull) {
+                if (want) {
+                    const uint32_t e = n_park + lane_prefix(mw);
+                    p_idx[e] = i;
+                    p_t[e] = h.t;
+                    p_id[e] = h.id;
+                }
+                n_park += (uint32_t)__builtin_popcountll(mw);
+            }
+            if (n_park >= 64u) {
+                n_park -= 64u;
+                walk_batch(n_park + lane, true);
+            }
+        }
+        if (n_park != 0u) {
+            walk_batch(lane, lane < n_park);
+            n_park = 0u;
+        }
+        __syncthreads();  // every append of this level is counted
+        const uint32_t tail = *tail_p;
+        n = tail < cap ? tail : cap;
+    }
+    if (overflow) atomicOr(flags, 1u);
+    __syncthreads();
+    if (tid == 0) blk_rays[b] += total;
+    const size_t plane = (size_t)F.n_streams * m;
+    for (uint32_t k = tid; k < 3u * mb; k += kBlock) {
+        const uint32_t c = k / mb, p = k - c * mb;
+        const unsigned long long v = lds_acc[c * m + p];
+        if (v) acc[(size_t)c * plane + (size_t)b * m + p] += v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_resolve(const unsigned long long *__restrict__ acc,
                                                     float *__restrict__ out, uint32_t npix, uint32_t spp,
                                                     uint32_t n_streams, uint32_t m) {
@@ -688,6 +863,12 @@ void launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const FrameParam
     else
         hipLaunchKernelGGL(k_pass<false>, dim3(K), dim3(kBlock), lds_plain, st, S, F, q0, q1, cap, s0, s_here, m, acc,
                            blk_rays, flags);
+}
+void launch_pass_bvh(hipStream_t st, uint32_t K, const DevScene &S, const FrameParams &F, const RayQueue &q0,
+                     const RayQueue &q1, uint32_t cap, uint32_t s0, uint32_t s_here, uint32_t m, unsigned long long *acc,
+                     unsigned long long *blk_rays, uint32_t *flags) {
+    hipLaunchKernelGGL(k_pass_bvh, dim3(K), dim3(kBlock), pass_bvh_lds_bytes(S, m), st, S, F, q0, q1, cap, s0, s_here, m,
+                       acc, blk_rays, flags);
 }
 void launch_scatter_chunks(hipStream_t st, const float *src, float *dst, uint32_t npix, uint32_t C, uint32_t n,
                            uint32_t j) {
