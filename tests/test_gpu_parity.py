@@ -632,11 +632,10 @@ def _render_flags(gpu, sc, w, h, spp, seed, flags, rays_per_pass=0, chunks=None)
     return out, st
 
 
-@pytest.mark.parametrize("sid", ["cornell", "three-spheres", "cartesian", "single-sphere"])
+@pytest.mark.parametrize("sid", ["cornell", "three-spheres", "cartesian", "single-sphere", "mesh"])
 def test_pass_kernel_equals_separate_kernels(gpu, sid):
-    """k_pass (a whole pass per launch, the default for scenes without BVH meshes) and the generate / intersect /
-    shade kernels give the same image bits and the same bounce count: one pass, many ragged passes, an interleaved
-    share of the frame."""
+    """k_pass / k_pass_bvh (a whole pass per launch, the default) and the generate / intersect / shade kernels give the
+    same image bits and the same bounce count: one pass, many ragged passes, an interleaved share of the frame."""
     sc = ptlib.load_scene_py(ptlib.scene_path(sid))
     for (w, h, spp, rpp, chunks) in [(96, 64, 24, 0, None), (97, 53, 50, 97 * 53 * 7, None), (96, 64, 9, 0, (96, 1, 3)),
                                      (33, 17, 3, 33 * 17, None)]:
