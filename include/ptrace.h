@@ -172,8 +172,8 @@ int pt_ctx_set_profiling(pt_ctx *ctx, int enabled);
  * picking / click-debug / orbit pivot (src/views/viewport_tab.rs:240-246, render_tab.rs:177-205).
  * Host arrays: o,d = n*3 floats; outputs may be NULL.  object_id = -1 on a miss
  * (intersect_scene -> None), tri_id = index into the object's triangle list or -1 for spheres.
- * Bit-for-bit agreement with the reference's intersect_scene is guaranteed for rays that start where the path
- * tracer's own rays start - inside the bounding box of the scene's objects and of the camera given to
+ * Bit-for-bit agreement with the reference's intersect_scene is guaranteed for rays like the path tracer's own:
+ * direction of unit length (the reference normalises every direction it casts) and origin where its rays start - inside the bounding box of the scene's objects and of the camera given to
  * pt_ctx_set_scene: the error bounds behind the BVH boxes and the bounding-sphere shortcuts assume that distance
  * scale (pt_host.cpp).  A picking ray from a camera far outside the scene still gets the nearest hit, but a hit that
  * only exists through f32 round-off of the reference's arithmetic at that distance may be resolved differently. */
