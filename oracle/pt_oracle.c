@@ -411,7 +411,19 @@ typedef struct {
     /* optional ray dump (every intersect_scene call): o(3) d(3) per ray */
     float *dump;
     uint64_t dump_cap, dump_n;
+    /* MOCK_RANDOM mode (mod.rs:31-51): when non-NULL every rand01() call takes the next entry of the reference's
+     * cyclic 9-value table, in the reference's own call order, instead of a Philox word */
+    uint64_t *mock_index;
 } rctx;
+
+/* MOCK_RANDOMS, mod.rs:33-43: f32 constants (the literals carry more digits than an f32 holds; rustc rounds each
+ * to the nearest f32, as the C compiler does with the f suffix) */
+static const float MOCK_RANDOMS[9] = {
+    0.75902418061906407f, 0.023879213030728041f, 0.21016190197770457f, 0.78814922184253244f, 0.56819568237964491f,
+    0.7689823904006352f,  0.16910304067812287f,  0.54519597695203492f, 0.63614169009490062f,
+};
+/* rand01() with MOCK_RANDOM = true: MOCK_RANDOMS[fetch_add(1) % 9] (mod.rs:47-51) */
+static inline float mock_rand01(uint64_t *index) { return MOCK_RANDOMS[(*index)++ % 9u]; }
 
 static v3 radiance(rctx *c, v3 ro, v3 rd, int depth, uint32_t branch) {
     if (c->cnt) c->cnt->ray_bounces++;
@@ -434,11 +446,14 @@ static v3 radiance(rctx *c, v3 ro, v3 rd, int depth, uint32_t branch) {
 
     int new_depth = depth + 1;
     float u[4];
-    draw4(c->seed, c->pixel, c->sample, (branch << 8) | (uint32_t)new_depth, u);
+    if (!c->mock_index) draw4(c->seed, c->pixel, c->sample, (branch << 8) | (uint32_t)new_depth, u);
+    /* each use below is one rand01() call of the reference, in its evaluation order; RAND(k) is Philox word k of this
+     * invocation, or, in MOCK_RANDOM mode, the next table entry at the moment the reference would call rand01() */
+#define RAND(k) (c->mock_index ? mock_rand01(c->mock_index) : u[k])
 
     /* Russian roulette, mod.rs:676-683 (the draw happens before the depth test: short-circuit &&) */
     if (new_depth > 5) {
-        if (u[0] < max_reflection && new_depth < MAX_DEPTH)
+        if (RAND(0) < max_reflection && new_depth < MAX_DEPTH)
             color = vscale(color, 1.0f / max_reflection);
         else
             return emission;
@@ -446,8 +461,8 @@ static v3 radiance(rctx *c, v3 ro, v3 rd, int depth, uint32_t branch) {
 
     v3 rest;
     if (object->reflect_type == PT_DIFFUSE) { /* mod.rs:687-715 */
-        float r1 = 2.0f * PI_F * u[1];
-        float r2 = u[2];
+        float r1 = 2.0f * PI_F * RAND(1);
+        float r2 = RAND(2);
         float r2s = sqrtf(r2);
         v3 w = normal_towards_ray;
         v3 uu = vnormalize(vcross(fabsf(w.x) > 0.1f ? V(0, 1, 0) : V(1, 0, 0), w));
@@ -480,7 +495,7 @@ static v3 radiance(rctx *c, v3 ro, v3 rd, int depth, uint32_t branch) {
             float rp = re / p;
             float tp = tr / (1.0f - p);
             if (new_depth > 2) {
-                if (u[1] < p)
+                if (RAND(1) < p)
                     rest = vscale(vmul(color, radiance(c, hit.intersection, refl_d, new_depth, branch)), rp);
                 else
                     rest = vscale(vmul(color, radiance(c, hit.intersection, tdir, new_depth, branch)), tp);
@@ -492,13 +507,14 @@ static v3 radiance(rctx *c, v3 ro, v3 rd, int depth, uint32_t branch) {
             }
         }
     }
+#undef RAND
     return vadd(emission, rest);
 }
 
 /* test_radiance's loop (test.rs:146-183): `n` samples of one fixed ray, sample i keyed (pixel, i) */
 void pto_radiance_mean(const pto_scene *s, const float o[3], const float d[3], uint64_t seed, uint32_t pixel,
                        uint32_t n, float out[3], pto_counters *cnt) {
-    rctx c = {s, seed, pixel, 0, cnt, NULL, 0, 0};
+    rctx c = {s, seed, pixel, 0, cnt, NULL, 0, 0, NULL};
     v3 acc = V(0, 0, 0);
     for (uint32_t i = 0; i < n; i++) {
         c.sample = i;
@@ -526,13 +542,18 @@ static cam_basis make_basis(const pt_camera *cam) {
 static inline float tent(float r) { return r < 1.0f ? sqrtf(r) - 1.0f : 1.0f - sqrtf(2.0f - r); }
 
 static void primary_ray(const cam_basis *cb, uint32_t width, uint32_t height, uint32_t pixel_index, uint32_t s,
-                        uint64_t seed, v3 *ro, v3 *rd) {
+                        uint64_t seed, uint64_t *mock_index, v3 *ro, v3 *rd) {
     uint32_t y = height - 1 - pixel_index / width;
     uint32_t x = pixel_index % width;
     float ysub = (float)((s / 2) % 2);
     float xsub = (float)(s % 2);
     float u[4];
-    draw4(seed, pixel_index, s, 0u, u);
+    if (mock_index) { /* two rand01() calls, r1 first (mod.rs:818-819) */
+        u[0] = mock_rand01(mock_index);
+        u[1] = mock_rand01(mock_index);
+    } else {
+        draw4(seed, pixel_index, s, 0u, u);
+    }
     float r1 = 2.0f * u[0];
     float r2 = 2.0f * u[1];
     float xfilter = tent(r1);
@@ -545,12 +566,12 @@ static void primary_ray(const cam_basis *cb, uint32_t width, uint32_t height, ui
 }
 
 static v3 render_pixel(const pto_scene *s, const cam_basis *cb, const pto_config *cfg, uint32_t pixel_index,
-                       pto_counters *cnt) {
-    rctx c = {s, cfg->seed, pixel_index, 0, cnt, NULL, 0, 0};
+                       pto_counters *cnt, uint64_t *mock_index) {
+    rctx c = {s, cfg->seed, pixel_index, 0, cnt, NULL, 0, 0, mock_index};
     v3 radiance_v = V(0, 0, 0);
     for (uint32_t smp = 0; smp < cfg->spp; smp++) {
         v3 ro, rd;
-        primary_ray(cb, cfg->width, cfg->height, pixel_index, smp, cfg->seed, &ro, &rd);
+        primary_ray(cb, cfg->width, cfg->height, pixel_index, smp, cfg->seed, mock_index, &ro, &rd);
         c.sample = smp;
         radiance_v = vadd(radiance_v, radiance(&c, ro, rd, 0, 1u));
     }
@@ -563,7 +584,7 @@ void pto_primary_ray(const pt_camera *cam, uint32_t width, uint32_t height, uint
                      uint32_t sample, uint64_t seed, float o[3], float d[3]) {
     cam_basis cb = make_basis(cam);
     v3 ro, rd;
-    primary_ray(&cb, width, height, pixel_index, sample, seed, &ro, &rd);
+    primary_ray(&cb, width, height, pixel_index, sample, seed, NULL, &ro, &rd);
     vst(o, ro);
     vst(d, rd);
 }
@@ -571,7 +592,7 @@ void pto_primary_ray(const pt_camera *cam, uint32_t width, uint32_t height, uint
 void pto_render_pixel(const pto_scene *s, const pto_config *cfg, uint32_t pixel_index, float out[3],
                       pto_counters *cnt) {
     cam_basis cb = make_basis(&s->camera);
-    vst(out, render_pixel(s, &cb, cfg, pixel_index, cnt));
+    vst(out, render_pixel(s, &cb, cfg, pixel_index, cnt, NULL));
 }
 
 /* Dump every ray the path tracer casts for the pixels [idx_begin, idx_end): used to test the HIP
@@ -579,12 +600,12 @@ void pto_render_pixel(const pto_scene *s, const pto_config *cfg, uint32_t pixel_
 uint64_t pto_dump_rays(const pto_scene *s, const pto_config *cfg, uint32_t idx_begin, uint32_t idx_end,
                        float *rays_od, uint64_t cap) {
     cam_basis cb = make_basis(&s->camera);
-    rctx c = {s, cfg->seed, 0, 0, NULL, rays_od, cap, 0};
+    rctx c = {s, cfg->seed, 0, 0, NULL, rays_od, cap, 0, NULL};
     for (uint32_t idx = idx_begin; idx < idx_end; idx++) {
         c.pixel = idx;
         for (uint32_t smp = 0; smp < cfg->spp; smp++) {
             v3 ro, rd;
-            primary_ray(&cb, cfg->width, cfg->height, idx, smp, cfg->seed, &ro, &rd);
+            primary_ray(&cb, cfg->width, cfg->height, idx, smp, cfg->seed, NULL, &ro, &rd);
             c.sample = smp;
             (void)radiance(&c, ro, rd, 0, 1u);
         }
@@ -635,7 +656,7 @@ int pto_render(const pto_scene *s, const pto_config *cfg, uint32_t idx_begin, ui
 #endif
         for (uint32_t i = 0; i < n; i++) {
             uint32_t idx = order[i];
-            v3 px = render_pixel(s, &cb, cfg, idx, &local);
+            v3 px = render_pixel(s, &cb, cfg, idx, &local, NULL);
             vst(out_rgb + 3 * (size_t)idx, px);
         }
 #ifdef _OPENMP
@@ -654,6 +675,99 @@ int pto_render(const pto_scene *s, const pto_config *cfg, uint32_t idx_begin, ui
     if (cnt_out) *cnt_out = total;
     free(order);
     return 0;
+}
+
+/* render() with MOCK_RANDOM = true (mod.rs:1017-1018): pixels 0..W*H in order on one thread, every rand01() call
+ * of the whole frame drawing from one global counter that starts at 0.  The frame a cargo holder gets from the
+ * reference after flipping that one constant; tools/mock_reference_ppm.py writes its PPM. */
+int pto_render_mock(const pto_scene *s, const pto_config *cfg, float *out_rgb, pto_counters *cnt_out, uint64_t *draws) {
+    cam_basis cb = make_basis(&s->camera);
+    pto_counters total;
+    memset(&total, 0, sizeof total);
+    uint64_t index = 0;
+    uint32_t n = cfg->width * cfg->height;
+    for (uint32_t idx = 0; idx < n; idx++) vst(out_rgb + 3 * (size_t)idx, render_pixel(s, &cb, cfg, idx, &total, &index));
+    if (cnt_out) *cnt_out = total;
+    if (draws) *draws = index;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ intersect_bounds / get_orbit_point */
+/* bounding_box_to_triangles (mod.rs:501-536) over the AABB of a triangle list as Mesh::new computes it (mod.rs:452-476) */
+void pto_mesh_bounding_box(const pt_triangle *tris, uint32_t n, pt_triangle out[12]) {
+    v3 mn = V(INFINITY, INFINITY, INFINITY), mx = V(-INFINITY, -INFINITY, -INFINITY);
+    for (uint32_t i = 0; i < n; i++) {
+        const float *vs[3] = {tris[i].a, tris[i].b, tris[i].c};
+        for (int k = 0; k < 3; k++) {
+            const float *p = vs[k];
+            if (p[0] < mn.x) mn.x = p[0];
+            if (p[1] < mn.y) mn.y = p[1];
+            if (p[2] < mn.z) mn.z = p[2];
+            if (p[0] > mx.x) mx.x = p[0];
+            if (p[1] > mx.y) mx.y = p[1];
+            if (p[2] > mx.z) mx.z = p[2];
+        }
+    }
+    const v3 vtx[8] = {V(mn.x, mn.y, mn.z), V(mx.x, mn.y, mn.z), V(mx.x, mx.y, mn.z), V(mn.x, mx.y, mn.z),
+                       V(mn.x, mn.y, mx.z), V(mx.x, mn.y, mx.z), V(mx.x, mx.y, mx.z), V(mn.x, mx.y, mx.z)};
+    static const int idx[12][3] = {{0, 1, 2}, {0, 2, 3}, {4, 6, 5}, {4, 7, 6}, {0, 4, 5}, {0, 5, 1},
+                                   {3, 2, 6}, {3, 6, 7}, {1, 5, 6}, {1, 6, 2}, {0, 3, 7}, {0, 7, 4}};
+    for (int i = 0; i < 12; i++) {
+        vst(out[i].a, vtx[idx[i][0]]);
+        vst(out[i].b, vtx[idx[i][1]]);
+        vst(out[i].c, vtx[idx[i][2]]);
+    }
+}
+
+/* SceneObjectData::intersect_bounds (mod.rs:282-290): the sphere itself, or Moller-Trumbore over the 12 triangles of
+ * Mesh.bounding_box (object-local, `boxes` holds 12 per object; entries of sphere objects are ignored) */
+static int object_intersect_bounds(const pt_object *o, const pt_triangle *box, v3 ro, v3 rd, hit_t *h) {
+    if (o->kind == PT_SPHERE) return intersect_sphere(vld(o->position), o->radius, ro, rd, h);
+    return intersect_triangles(ro, rd, vld(o->position), box, 12, h, NULL);
+}
+
+void pto_intersect_bounds_batch(const pto_scene *s, const pt_triangle *boxes, uint32_t object, const float *o,
+                                const float *d, uint32_t n, int32_t *hit, float *t, float *x, float *nrm) {
+    for (uint32_t i = 0; i < n; i++) {
+        hit_t h;
+        int f = object_intersect_bounds(&s->objs[object], boxes + 12 * (size_t)object, vld(o + 3 * i), vld(d + 3 * i), &h);
+        if (!f) {
+            h.distance = 0.0f;
+            h.intersection = V(0, 0, 0);
+            h.normal = V(0, 0, 0);
+        }
+        if (hit) hit[i] = f;
+        if (t) t[i] = h.distance;
+        if (x) vst(x + 3 * i, h.intersection);
+        if (nrm) vst(nrm + 3 * i, h.normal);
+    }
+}
+
+/* get_orbit_point (src/views/viewport_tab.rs:401-431): objects in reverse order; an object whose bounds are hit
+ * contributes its real hit if it has one, else the bounds hit; strict < keeps the first of equal distances */
+void pto_orbit_point_batch(const pto_scene *s, const pt_triangle *boxes, const float *o, const float *d, uint32_t n,
+                           int32_t *found, float *point, int32_t *object_id, float *t) {
+    for (uint32_t i = 0; i < n; i++) {
+        v3 ro = vld(o + 3 * i), rd = vld(d + 3 * i);
+        int have = 0;
+        hit_t best;
+        int32_t best_obj = -1;
+        memset(&best, 0, sizeof best);
+        for (int32_t k = (int32_t)s->n_objs - 1; k >= 0; k--) {
+            hit_t hb, ho;
+            if (!object_intersect_bounds(&s->objs[k], boxes + 12 * (size_t)k, ro, rd, &hb)) continue;
+            hit_t nh = object_intersect(&s->objs[k], s->tris, ro, rd, &ho, NULL, NULL) ? ho : hb;
+            if (!have || nh.distance < best.distance) {
+                best = nh;
+                best_obj = k;
+                have = 1;
+            }
+        }
+        if (found) found[i] = have;
+        if (object_id) object_id[i] = best_obj;
+        if (t) t[i] = have ? best.distance : 0.0f;
+        if (point) vst(point + 3 * i, have ? best.intersection : V(0, 0, 0));
+    }
 }
 
 int pto_max_threads(void) {

@@ -62,6 +62,15 @@ uint64_t pto_dump_rays(const pto_scene *s, const pto_config *cfg, uint32_t idx_b
                        float *rays_od, uint64_t cap);
 int pto_render(const pto_scene *s, const pto_config *cfg, uint32_t idx_begin, uint32_t idx_end, float *out_rgb,
                int threads, pto_counters *cnt_out, double *seconds);
+/* render() with MOCK_RANDOM = true (mod.rs:31-51, 1017-1018): sequential pixels, one global cyclic 9-value table */
+int pto_render_mock(const pto_scene *s, const pto_config *cfg, float *out_rgb, pto_counters *cnt_out, uint64_t *draws);
+/* Mesh::new's bounding_box (mod.rs:452-476, 501-536), SceneObjectData::intersect_bounds (mod.rs:282-290) and
+ * get_orbit_point (src/views/viewport_tab.rs:401-431); `boxes` = 12 object-local triangles per object */
+void pto_mesh_bounding_box(const pt_triangle *tris, uint32_t n, pt_triangle out[12]);
+void pto_intersect_bounds_batch(const pto_scene *s, const pt_triangle *boxes, uint32_t object, const float *o,
+                                const float *d, uint32_t n, int32_t *hit, float *t, float *x, float *nrm);
+void pto_orbit_point_batch(const pto_scene *s, const pt_triangle *boxes, const float *o, const float *d, uint32_t n,
+                           int32_t *found, float *point, int32_t *object_id, float *t);
 int pto_max_threads(void);
 size_t pto_format_ppm(const float *rgb, uint32_t width, uint32_t height, uint32_t spp, const char *scene_id,
                       uint64_t seconds, char *buf, size_t cap);

@@ -121,6 +121,15 @@ def oracle():
                              C.POINTER(PtoCounters), C.POINTER(C.c_double)]
     L.pto_render.restype = C.c_int
     L.pto_max_threads.restype = C.c_int
+    L.pto_render_mock.argtypes = [C.POINTER(PtoScene), C.POINTER(PtoConfig), fp, C.POINTER(PtoCounters), u64p]
+    L.pto_render_mock.restype = C.c_int
+    L.pto_mesh_bounding_box.argtypes = [C.POINTER(PtTriangle), C.c_uint32, C.POINTER(PtTriangle)]
+    L.pto_mesh_bounding_box.restype = None
+    L.pto_intersect_bounds_batch.argtypes = [C.POINTER(PtoScene), C.POINTER(PtTriangle), C.c_uint32, fp, fp, C.c_uint32,
+                                             i32p, fp, fp, fp]
+    L.pto_intersect_bounds_batch.restype = None
+    L.pto_orbit_point_batch.argtypes = [C.POINTER(PtoScene), C.POINTER(PtTriangle), fp, fp, C.c_uint32, i32p, fp, i32p, fp]
+    L.pto_orbit_point_batch.restype = None
     L.pto_format_ppm.argtypes = [fp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint64, C.c_char_p,
                                  C.c_size_t]
     L.pto_format_ppm.restype = C.c_size_t
@@ -325,6 +334,49 @@ def load_scene_py(path, base_dir=None, triangulate=False):
                               len(tlist), bs_c, bs_r))
         tris.extend(tlist)
     return Scene(d["id"], cam, objs, tris)
+
+
+def oracle_boxes(scene):
+    """Mesh.bounding_box of every object as Mesh::new computes it (12 object-local triangles per object; zeros for
+    spheres): the `boxes` argument of pto_intersect_bounds_batch / pto_orbit_point_batch."""
+    L = oracle()
+    boxes = (PtTriangle * (12 * max(1, scene.n_objs)))()
+    for i in range(scene.n_objs):
+        o = scene.objs[i]
+        if o.kind != PT_MESH:
+            continue
+        arr = (PtTriangle * o.tri_count)(*[scene.tris[o.tri_offset + k] for k in range(o.tri_count)])
+        out = (PtTriangle * 12)()
+        L.pto_mesh_bounding_box(arr, o.tri_count, out)
+        for k in range(12):
+            boxes[12 * i + k] = out[k]
+    return boxes
+
+
+def oracle_render_mock(scene, width, height, spp):
+    """The reference's frame with MOCK_RANDOM = true (mod.rs:31-51): image, counters, number of rand01() calls."""
+    L = oracle()
+    cfg = PtoConfig(width, height, spp, 0, 0)
+    out = np.zeros((width * height, 3), dtype=np.float32)
+    cnt = PtoCounters()
+    draws = C.c_uint64()
+    ps = scene.pto()
+    assert L.pto_render_mock(C.byref(ps), C.byref(cfg), _np_f(out), C.byref(cnt), C.byref(draws)) == 0
+    return out, cnt, draws.value
+
+
+def oracle_intersect(scene, o, d):
+    """intersect_scene ray by ray: (t, object_id, tri_id, x, n) arrays."""
+    L = oracle()
+    o = np.ascontiguousarray(o, dtype=np.float32).reshape(-1, 3)
+    d = np.ascontiguousarray(d, dtype=np.float32).reshape(-1, 3)
+    m = len(o)
+    t, oid, tid = np.zeros(m, np.float32), np.zeros(m, np.int32), np.zeros(m, np.int32)
+    x, nr = np.zeros((m, 3), np.float32), np.zeros((m, 3), np.float32)
+    ps = scene.pto()
+    L.pto_intersect_batch(C.byref(ps), _np_f(o), _np_f(d), m, _np_f(t), oid.ctypes.data_as(i32p),
+                          tid.ctypes.data_as(i32p), _np_f(x), _np_f(nr))
+    return t, oid, tid, x, nr
 
 
 def scene_path(sid):

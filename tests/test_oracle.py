@@ -173,13 +173,165 @@ def test_mesh_bounding_sphere_matches_stored():
         assert rad.value == o.bs_radius, i
 
 
+def _siphash_py(c_rounds, d_rounds, k0, k1, data):
+    """SipHash-c-d (Aumasson & Bernstein), written independently of oracle/ and of the product, for the KATs below."""
+    M = (1 << 64) - 1
+    rotl = lambda x, b: ((x << b) | (x >> (64 - b))) & M
+    v = [k0 ^ 0x736f6d6570736575, k1 ^ 0x646f72616e646f6d, k0 ^ 0x6c7967656e657261, k1 ^ 0x7465646279746573]
+
+    def rnd():
+        v[0] = (v[0] + v[1]) & M; v[1] = rotl(v[1], 13); v[1] ^= v[0]; v[0] = rotl(v[0], 32)
+        v[2] = (v[2] + v[3]) & M; v[3] = rotl(v[3], 16); v[3] ^= v[2]
+        v[0] = (v[0] + v[3]) & M; v[3] = rotl(v[3], 21); v[3] ^= v[0]
+        v[2] = (v[2] + v[1]) & M; v[1] = rotl(v[1], 17); v[1] ^= v[2]; v[2] = rotl(v[2], 32)
+
+    n = len(data)
+    for i in range(0, n - n % 8, 8):
+        m = int.from_bytes(data[i:i + 8], "little")
+        v[3] ^= m
+        for _ in range(c_rounds):
+            rnd()
+        v[0] ^= m
+    b = ((n & 0xff) << 56) | int.from_bytes(data[n - n % 8:], "little")
+    v[3] ^= b
+    for _ in range(c_rounds):
+        rnd()
+    v[0] ^= b
+    v[2] ^= 0xff
+    for _ in range(d_rounds):
+        rnd()
+    return v[0] ^ v[1] ^ v[2] ^ v[3]
+
+
 def test_siphash13_kat():
-    """Rust DefaultHasher (SipHash-1-3, zero key).  Known value: hashing nothing -> 0x1e924b9d737700d7? is not
-    relied upon; pin against the reference SipHash-1-3 test vector property instead: 8 zero bytes differ from
-    empty and the function is deterministic."""
-    a = L.pto_siphash13(b"", 0)
-    b = L.pto_siphash13(b"\0" * 8, 8)
-    assert a != b and a == L.pto_siphash13(b"", 0)
+    """Image.hash is Rust's DefaultHasher = SipHash-1-3 with a zero key (mod.rs:916-926).  The Python restatement
+    above is pinned on the published SipHash-2-4 vector (reference paper, key 00..0f, message 00..0e) and on the first
+    SipHash-1-3 vector of Rust's own library tests (library/core/tests/hash/sip.rs, key 00..0f, empty message:
+    dc c4 0f 05 58 01 ac ab); the oracle then has to agree with it, zero key, on fixed and random messages."""
+    k0, k1 = 0x0706050403020100, 0x0f0e0d0c0b0a0908
+    assert _siphash_py(2, 4, k0, k1, bytes(range(15))) == 0xa129ca6149be45e5
+    assert _siphash_py(1, 3, k0, k1, b"") == 0xabac0158050fc4dc
+    assert L.pto_siphash13(b"", 0) == 0xd1fba762150c532c == _siphash_py(1, 3, 0, 0, b"")
+    rng = np.random.default_rng(5)
+    for n in (1, 7, 8, 9, 12, 16, 31, 4096):
+        msg = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+        assert L.pto_siphash13(msg, n) == _siphash_py(1, 3, 0, 0, msg), n
+    img = rng.random(33, dtype=np.float32)
+    assert L.pto_image_hash(_np_f(img), img.size) == _siphash_py(1, 3, 0, 0, img.tobytes())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# hand-derived KATs for what the reference's tests do not reach (tests/kats.py): triangles, the gate, the tie rules
+import kats
+
+
+@pytest.mark.parametrize("name,build,o,d,want", kats.CASES, ids=[c[0] for c in kats.CASES])
+def test_hand_derived_kats_on_the_oracle(name, build, o, d, want):
+    sc = build()
+    t, oid, tid, x, n = ptlib.oracle_intersect(sc, o, d)
+    if want is None:
+        assert oid[0] == -1, (name, oid[0], t[0])
+        return
+    assert (oid[0], tid[0]) == (want["object_id"], want["tri_id"]), name
+    assert t[0] == np.float32(want["t"]), (name, t[0])
+    assert list(x[0]) == [np.float32(v) for v in want["x"]], (name, x[0])
+    assert list(n[0]) == [np.float32(v) for v in want["n"]], (name, n[0])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# MOCK_RANDOM (mod.rs:31-51): the reference's only deterministic mode, restated so that a cargo holder can diff a frame
+def test_mock_random_mode():
+    """rand01() with MOCK_RANDOM = true walks a 9-entry table through one global counter, pixels in index order on one
+    thread (mod.rs:1017-1018).  Checked here: determinism; the draw count lies between the bounds the path's rand01()
+    calls allow (2 per sample, 2 per surviving diffuse bounce, 1 per roulette); the PPM header of the reference's
+    writer; and that this stream is not the Philox stream of the parity contract."""
+    sc = ptlib.load_scene_py(ptlib.scene_path("two-spheres"))  # diffuse spheres only: every bounce draws r1, r2
+    w, h, spp = 24, 16, 4
+    img, cnt, draws = ptlib.oracle_render_mock(sc, w, h, spp)
+    img2, cnt2, draws2 = ptlib.oracle_render_mock(sc, w, h, spp)
+    assert np.array_equal(img, img2) and draws == draws2 and cnt.ray_bounces == cnt2.ray_bounces
+    samples = w * h * spp
+    hits = cnt.ray_bounces - cnt.misses
+    assert hits > 0 and img.max() > 0.0
+    # a hit at new_depth <= 5 draws r1, r2; at new_depth > 5 the roulette number first and r1, r2 only if it survives
+    assert 2 * samples < draws <= 2 * samples + 3 * hits
+    # the counter is global: the frame's first row rendered as a frame of its own geometry would restart at entry 0;
+    # here the same frame at twice the samples must not simply repeat the 4-spp stream (9 does not divide the draws)
+    img8, _, draws8 = ptlib.oracle_render_mock(sc, w, h, 2 * spp)
+    assert draws8 > draws and not np.array_equal(img8, img)
+    ppm_len = L.pto_format_ppm(_np_f(img), w, h, spp, b"two-spheres", 0, None, 0)
+    buf = C.create_string_buffer(ppm_len)
+    assert L.pto_format_ppm(_np_f(img), w, h, spp, b"two-spheres", 0, buf, ppm_len) == ppm_len
+    assert buf.raw.startswith(b"P3\n# samplesPerPixel: 4, resolution_y: 16, scene_id: two-spheres\n# rendering time: 0 s\n24 16\n255\n")
+    # Philox frames (the parity contract of the GPU path) are a different stream: not the same picture
+    ph, _, _ = ptlib.oracle_render(sc, w, h, spp, 1)
+    assert not np.array_equal(ph, img)
+
+
+def test_mock_random_first_sample_by_hand():
+    """First sample of pixel 0 of single-sphere.json at 4x4, by hand from mod.rs:805-843 with the first two table
+    entries (0.75902418, 0.023879213): r1 = 1.5180483 >= 1 -> xfilter = 1 - sqrt(2 - r1); r2 = 0.047758426 < 1 ->
+    yfilter = sqrt(r2) - 1.  Pixel 0 is x = 0, y = H-1 = 3 (mod.rs:805-806).  The ray is compared with the oracle's
+    through its own primary-ray arithmetic evaluated in numpy f32."""
+    sc = ptlib.load_scene_py(ptlib.scene_path("single-sphere"))
+    f = np.float32
+    r1, r2 = f(2.0) * f(0.75902418061906407), f(2.0) * f(0.023879213030728041)
+    xf = f(1.0) - np.sqrt(f(2.0) - r1)
+    yf = np.sqrt(r2) - f(1.0)
+    sx = (f(0) + f(0.5) * (f(0.5) + f(0) + xf)) / f(4) - f(0.5)
+    sy = (f(3) + f(0.5) * (f(0.5) + f(0) + yf)) / f(4) - f(0.5)
+    lens, su, sv = (C.c_float * 3)(), (C.c_float * 3)(), (C.c_float * 3)()
+    L.pto_camera_basis(C.byref(sc.cam), lens, su, sv)
+    pos = np.array(list(sc.cam.position), np.float32)
+    sensor = (pos + np.array(list(su), np.float32) * sx) + np.array(list(sv), np.float32) * sy
+    dvec = np.array(list(lens), np.float32) - sensor
+    dlen = np.sqrt((dvec[0] * dvec[0] + dvec[1] * dvec[1]) + dvec[2] * dvec[2])
+    dvec = dvec * (f(1.0) / dlen)
+    # with 1 spp the whole 4x4 frame makes 16 primary rays; single-sphere has one emissive diffuse sphere: a ray that
+    # hits it returns emission + color * radiance(next), so pixel values depend on the draw order as well
+    img, cnt, draws = ptlib.oracle_render_mock(sc, 4, 4, 1)
+    t, oid, _, _, _ = ptlib.oracle_intersect(sc, list(lens), dvec)
+    # pixel 0 is a corner of the frame: its ray misses the unit sphere at the origin -> exactly 2 draws, black
+    assert oid[0] == -1 and list(img[0]) == [0.0, 0.0, 0.0]
+    assert draws >= 32
+
+
+def test_intersect_bounds_and_orbit_point():
+    """SceneObjectData::intersect_bounds (mod.rs:282-290) and get_orbit_point (viewport_tab.rs:401-431) by hand on the
+    unit triangle: its Mesh::new box is the degenerate slab [0,1]x[0,1]x{0}; a ray through (0.75, 0.75) misses the
+    triangle (u + v = 1.5) but hits box triangle (0,1,2) = (0,0,0),(1,0,0),(1,1,0) at t = 1 - the orbit point falls
+    back to the bounds hit; through (0.25, 0.25) the real hit is used."""
+    sc = kats.mesh_scene([kats.UNIT])
+    boxes = ptlib.oracle_boxes(sc)
+    assert [list(boxes[0].a), list(boxes[0].b), list(boxes[0].c)] == [[0, 0, 0], [1, 0, 0], [1, 1, 0]]
+    assert [list(boxes[1].a), list(boxes[1].b), list(boxes[1].c)] == [[0, 0, 0], [1, 1, 0], [0, 1, 0]]
+    o = np.array([[0.75, 0.75, 1.0], [0.25, 0.25, 1.0], [2.0, 2.0, 1.0]], np.float32)
+    d = np.array([[0, 0, -1.0]] * 3, np.float32)
+    hit = np.zeros(3, np.int32)
+    t, x, n = np.zeros(3, np.float32), np.zeros((3, 3), np.float32), np.zeros((3, 3), np.float32)
+    ps = sc.pto()
+    L.pto_intersect_bounds_batch(C.byref(ps), boxes, 0, _np_f(o), _np_f(d), 3, hit.ctypes.data_as(ptlib.i32p), _np_f(t),
+                                 _np_f(x), _np_f(n))
+    assert list(hit) == [1, 1, 0] and list(t[:2]) == [1.0, 1.0]
+    assert list(x[0]) == [0.75, 0.75, 0.0]
+    found, obj = np.zeros(3, np.int32), np.zeros(3, np.int32)
+    pt, tt = np.zeros((3, 3), np.float32), np.zeros(3, np.float32)
+    L.pto_orbit_point_batch(C.byref(ps), boxes, _np_f(o), _np_f(d), 3, found.ctypes.data_as(ptlib.i32p), _np_f(pt),
+                            obj.ctypes.data_as(ptlib.i32p), _np_f(tt))
+    assert list(found) == [1, 1, 0] and list(obj) == [0, 0, -1]
+    assert list(pt[0]) == [0.75, 0.75, 0.0] and list(pt[1]) == [0.25, 0.25, 0.0]
+    # shipped scene: the boxes Mesh::new computes are the ones the reference serialised into cornell.json
+    import json
+    cj = json.load(open(ptlib.scene_path("cornell")))
+    sc2 = ptlib.load_scene_py(ptlib.scene_path("cornell"))
+    b2 = ptlib.oracle_boxes(sc2)
+    for i, od in enumerate(cj["objects"]):
+        if "Mesh" not in od["type_"]:
+            continue
+        stored = od["type_"]["Mesh"]["bounding_box"]
+        for k in range(12):
+            for key in "abc":
+                assert [np.float32(v) for v in stored[k][key]] == list(getattr(b2[12 * i + k], key)), (i, k, key)
 
 
 # ---------------------------------------------------------------------------------------------------------------
