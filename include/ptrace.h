@@ -24,17 +24,18 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 2
+#define PT_ABI_VERSION 3
 
 /* status codes (reference behaviour: unwrap() panics, mod.rs:96,309,1032,1042,1093) */
 #define PT_OK 0
 #define PT_ERR_INVALID (-1)    /* bad argument / malformed scene */
 #define PT_ERR_NO_DEVICE (-2)  /* no HIP device (the product never falls back to the CPU) */
 #define PT_ERR_HIP (-3)        /* a HIP runtime call failed; text in pt_last_error() */
-#define PT_CANCELLED (-4)      /* *cancel became non-zero; framebuffer holds the passes done so far */
+#define PT_CANCELLED (-4)      /* *cancel became non-zero; framebuffer = the samples accumulated so far / their count */
 #define PT_ERR_OVERFLOW (-5)   /* a ray queue overflowed (cannot happen with the sizes pt_render picks) */
 #define PT_ERR_IO (-6)         /* file could not be read / written */
 #define PT_ERR_PARSE (-7)      /* scene JSON / OFF syntax or shape error */
+#define PT_ERR_COMM (-8)       /* an RCCL call failed (pt_comm_*); text in pt_last_error() */
 
 /* ReflectType — enum order of src/render/mod.rs:71-76 */
 #define PT_DIFFUSE 0u
@@ -113,8 +114,12 @@ typedef struct pt_config {
     uint32_t chunk_pixels;
     uint32_t chunk_first;
     uint32_t chunk_step;
-    uint32_t reserved;
+    /* Minimum interval between two progress callbacks, in milliseconds.  0 = 500, the reference's RenderUpdate cadence
+     * (mod.rs:965-982); PT_PROGRESS_EVERY_PASS = at every pass boundary (a few milliseconds apart).  The cancel byte is
+     * read at every pass boundary whatever this says (the reference polls it every 100 ms, mod.rs:947-958). */
+    uint32_t progress_ms;
 } pt_config;
+#define PT_PROGRESS_EVERY_PASS 0xffffffffu
 
 typedef struct pt_stats {
     uint64_t ray_bounces;        /* number of intersect_scene evaluations (mod.rs:663), exact */
@@ -127,7 +132,11 @@ typedef struct pt_stats {
     double ms_intersect; /* HIP-event time summed over those launches (only if PT profiling on) */
 } pt_stats;
 
-/* progress callback: fraction in [0,1]; invoked on the calling thread between passes */
+/* Progress callback: fraction in [0,1], between passes, at most every pt_config.progress_ms, and once with 1.0 when the
+ * frame is complete.  pt_ctx_render invokes it on the calling thread; pt_render_multi and PT_FLAG_PIPELINES render on
+ * worker threads and invoke it from the worker of rank / pipeline 0 - a GUI host has to marshal it.  It may raise the
+ * cancel byte: the render then stops at that boundary.  It may call pt_ctx_snapshot on the context it was given to
+ * (not under PT_FLAG_PIPELINES, where the accumulators live in child contexts: the snapshot reports an error). */
 typedef void (*pt_progress_fn)(void *user, float fraction);
 
 typedef struct pt_ctx pt_ctx;
@@ -155,7 +164,10 @@ uint32_t pt_config_pixels(const pt_config *cfg);
 /* Render the band [idx_begin, idx_end) (or this rank's chunks of it) into DEVICE memory: d_out_rgb holds
  * pt_config_pixels(cfg)*3 floats, pixel k of the call at element k*3+c, linear, clamped to [0,1] — for an
  * un-chunked band the memory image of the reference's Vec<Vec3> slice (mod.rs:1013-1014, 852-856).
- * `hip_stream` is a hipStream_t (NULL = the context's own stream).  Blocking. */
+ * `hip_stream` is a hipStream_t (NULL = the context's own stream).  Blocking.
+ * Cancel (both backends): *cancel is read between passes (wavefront: one pass = one launch of a few ms; megakernel: one
+ * round of about 0.1 s).  On PT_CANCELLED the buffer holds every pixel averaged over the samples that were accumulated
+ * (stats->samples / pixels of the call), all zero if none - the picture pt_ctx_snapshot would have given. */
 int pt_ctx_render(pt_ctx *ctx, const pt_config *cfg, void *d_out_rgb, void *hip_stream,
                   const volatile uint8_t *cancel, pt_progress_fn cb, void *user, pt_stats *stats);
 
@@ -180,6 +192,23 @@ int pt_ctx_set_profiling(pt_ctx *ctx, int enabled);
 int pt_ctx_intersect(pt_ctx *ctx, const float *o, const float *d, uint32_t n, float *t,
                      int32_t *object_id, int32_t *tri_id, float *x, float *normal);
 
+/* SceneObjectData::intersect_bounds (mod.rs:282-290) of object `object` for n rays: a sphere is tested itself
+ * (intersect_sphere), a mesh through Triangle::intersect over the 12 triangles of Mesh.bounding_box.  hit[i] = 1/0;
+ * t / x / normal as Hit holds them (zero on a miss).  Outputs may be NULL. */
+int pt_ctx_intersect_bounds(pt_ctx *ctx, uint32_t object, const float *o, const float *d, uint32_t n, int32_t *hit,
+                            float *t, float *x, float *normal);
+/* get_orbit_point (src/views/viewport_tab.rs:401-431): objects from the last to the first; an object whose bounds are
+ * hit contributes its real hit if it has one, else the bounds hit; the nearest (strict <) wins.  found[i] = 1/0, point =
+ * hit.intersection, object_id = the object that supplied it (-1), t = its distance. */
+int pt_ctx_orbit_point(pt_ctx *ctx, const float *o, const float *d, uint32_t n, int32_t *found, float *point,
+                       int32_t *object_id, float *t);
+/* Mesh.bounding_box of a mesh object (12 object-local triangles).  pt_ctx_set_scene computes it as Mesh::new does
+ * (mod.rs:452-476, 501-536); an inline Mesh of a scene file carries its own (deserialised verbatim, mod.rs:440-448) -
+ * pass that one here (pt_scene_bounding_box) when it may differ. */
+int pt_ctx_set_mesh_bounds(pt_ctx *ctx, uint32_t object, const pt_triangle box[12]);
+/* bounding_box_to_triangles over the AABB of the triangles, as Mesh::new stores it (mod.rs:452-476, 501-536) */
+int pt_mesh_bounding_box(const pt_triangle *tris, uint32_t n_tris, pt_triangle out[12]);
+
 /* Diagnostics: evaluate the device's numerics contract (sin, cos, sqrt, 1/x on in[i]; Philox block for
  * counter (i, bits(in[i]), (i<<8)|(i&15), 0), key 0x0123456789abcdef) so tests can compare it bit for bit
  * with the host.  Host arrays of n (out_philox: 4n). */
@@ -195,11 +224,13 @@ int pt_render(const pt_config *cfg, const pt_camera *cam, const pt_object *objs,
               const pt_triangle *tris, uint32_t n_tris, float *out_rgb,
               const volatile uint8_t *cancel, pt_progress_fn cb, void *user, pt_stats *stats);
 
-/* The same frame cut into n_ranks contiguous bands, one host thread and one context per band, band r on device
- * r mod pt_device_count(): single-process multi-GPU for hosts that want the image in HOST memory (the CLI).
- * Each band is downloaded straight into its slice of out_rgb, so no device-to-device collective is involved;
- * a host that keeps the framebuffer on the GPUs runs one process per GPU over pt_ctx_render and gathers the
- * bands with RCCL (bench.py).  The image is bit-identical for every n_ranks. */
+/* The same frame dealt to n_ranks ranks row by row - rank r renders image rows r, r+n_ranks, ... of the band (the
+ * interleaved partition of pt_config.chunk_*: contiguous parts of a picture differ in cost) - one host thread and one
+ * context per rank, rank r on device r mod pt_device_count(): single-process multi-GPU for hosts that want the image
+ * in HOST memory (the CLI).  Each rank downloads its rows and copies them to their places in out_rgb, so no
+ * device-to-device collective is involved; a host that keeps the framebuffer on the GPUs runs one process per GPU over
+ * pt_ctx_render and gathers with pt_comm_gather_frame (RCCL) below.  The image is bit-identical for every n_ranks.
+ * The progress callback comes from rank 0's worker thread. */
 int pt_render_multi(const pt_config *cfg, uint32_t n_ranks, const pt_camera *cam, const pt_object *objs,
                     uint32_t n_objs, const pt_triangle *tris, uint32_t n_tris, float *out_rgb,
                     const volatile uint8_t *cancel, pt_progress_fn cb, void *user, pt_stats *stats);
@@ -209,6 +240,23 @@ int pt_render_multi(const pt_config *cfg, uint32_t n_ranks, const pt_camera *cam
  * d_out_rgb (band layout) and reports how many samples per pixel it holds.  The reference's snapshot is a
  * random subset of finished pixels; this one is every pixel at partial spp. */
 int pt_ctx_snapshot(pt_ctx *ctx, void *d_out_rgb, uint32_t *spp_done);
+
+/* ---- the one collective of the path: the framebuffer gather over RCCL (xGMI) ---------------------------------
+ * One process (or thread) per GPU renders its rows with pt_ctx_render (chunk_first = rank, chunk_step = n_ranks) into
+ * device memory; pt_comm_gather_frame then gives EVERY rank the whole frame in device memory: one in-place
+ * ncclAllGather of the rank buffers (padded to the largest) and one kernel that puts the rows back in framebuffer order.
+ * librccl is loaded on first use (dlopen; PT_RCCL_LIB overrides the name), so hosts that never gather do not need it. */
+typedef struct pt_comm pt_comm;
+#define PT_COMM_ID_BYTES 128
+/* rank 0: a fresh id (ncclGetUniqueId); the host carries the bytes to the other ranks by its own means */
+int pt_comm_unique_id(uint8_t id[PT_COMM_ID_BYTES]);
+/* every rank, collectively: ncclCommInitRank on `device` */
+int pt_comm_create(int device, int rank, int n_ranks, const uint8_t id[PT_COMM_ID_BYTES], pt_comm **out);
+void pt_comm_destroy(pt_comm *comm);
+/* cfg: the frame (width, height, band) and the chunk size the ranks rendered with (chunk_pixels; chunk_first /
+ * chunk_step are taken from the communicator).  d_local_rgb: this rank's pt_ctx_render output; d_frame_rgb: band
+ * pixels * 3 floats on this rank's device.  `hip_stream`: NULL = the communicator's own stream.  Blocking. */
+int pt_comm_gather_frame(pt_comm *comm, const pt_config *cfg, const void *d_local_rgb, void *d_frame_rgb, void *hip_stream);
 
 /* Image.hash (mod.rs:897-926): Rust's DefaultHasher (SipHash-1-3, zero key) over the f32 bit patterns of the
  * pixels in order; the GUI uses it to invalidate its canvas cache (src/views/render_tab.rs:248-256). */
@@ -246,6 +294,9 @@ const char *pt_scene_id(const pt_scene *s);
 const pt_camera *pt_scene_camera(const pt_scene *s);
 const pt_object *pt_scene_objects(const pt_scene *s, uint32_t *n);
 const pt_triangle *pt_scene_triangles(const pt_scene *s, uint32_t *n);
+/* Mesh.bounding_box of object i as the scene file stored it, or as Mesh::new computes it for MeshFile objects and meshes
+ * built through the API; NULL for spheres.  12 triangles, valid until the scene is freed. */
+const pt_triangle *pt_scene_bounding_box(const pt_scene *s, uint32_t object);
 
 /* load_off (load_off.rs:8-85): returns a malloc'ed triangle array (free with pt_free). */
 int pt_load_off(const char *path, float scale, pt_triangle **tris, uint32_t *n_tris);

@@ -39,7 +39,7 @@ class pt_config(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("spp", C.c_uint32), ("backend", C.c_uint32),
                 ("seed", C.c_uint64), ("idx_begin", C.c_uint32), ("idx_end", C.c_uint32),
                 ("rays_per_pass", C.c_uint32), ("flags", C.c_uint32), ("chunk_pixels", C.c_uint32),
-                ("chunk_first", C.c_uint32), ("chunk_step", C.c_uint32), ("reserved", C.c_uint32)]
+                ("chunk_first", C.c_uint32), ("chunk_step", C.c_uint32), ("progress_ms", C.c_uint32)]
 
 
 class pt_stats(C.Structure):

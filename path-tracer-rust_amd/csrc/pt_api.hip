@@ -56,11 +56,41 @@ struct DevBuf {
 
 using namespace pt;
 
+// Tuning switches (A/B runs, profiling).  Read from the environment ONCE, when a context is created, and kept with the
+// context: a frame never sees two different answers.  PT_DEBUG (ablation switches that change the image) exists only in
+// builds made with -DPT_ALLOW_DEBUG; the shipped library ignores it.
+struct Tuning {
+    bool pass_kernel = true;   // PT_PASS_KERNEL=0: generate / intersect / shade as separate kernels
+    bool pass_bvh = true;      // PT_PASS_BVH=0: BVH scenes through the separate kernels
+    bool bvh_lds = false;      // PT_BVH_LDS=1: stage BVH nodes in LDS (separate kernels only)
+    uint32_t leaf_quorum = 12; // PT_LEAF_QUORUM: lanes on a leaf that send a walking wave to the triangle code
+    uint64_t streams = 0;      // PT_STREAMS: ray streams per pass (0 = derived from the frame)
+    uint32_t debug = 0;
+};
+static Tuning read_tuning() {
+    Tuning t;
+    auto num = [](const char *name, long long dflt) {
+        const char *e = getenv(name);
+        return e ? atoll(e) : dflt;
+    };
+    t.pass_kernel = num("PT_PASS_KERNEL", 1) != 0;
+    t.pass_bvh = num("PT_PASS_BVH", 1) != 0;
+    t.bvh_lds = num("PT_BVH_LDS", 0) != 0;
+    t.leaf_quorum = (uint32_t)num("PT_LEAF_QUORUM", 12);
+    const long long st = num("PT_STREAMS", 0);
+    t.streams = st > 0 ? (uint64_t)st : 0;
+#ifdef PT_ALLOW_DEBUG
+    t.debug = (uint32_t)num("PT_DEBUG", 0);
+#endif
+    return t;
+}
+
 struct pt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool has_scene = false;
     bool profiling = false;
+    Tuning tune;
     pt_camera cam{};
     DevScene scene{};
     DevBuf<ObjRec> d_objs;
@@ -70,6 +100,15 @@ struct pt_ctx {
     DevBuf<TriShade> d_tshade;
     DevBuf<BvhNode> d_nodes;
     uint32_t n_bvh_nodes = 0;
+    // Mesh.bounding_box of every object (12 object-local triangles each; Mesh::new's unless pt_ctx_set_mesh_bounds gave
+    // the stored ones) and their device form (6 pair records per object), for intersect_bounds / orbit-point queries
+    std::vector<pt_triangle> h_boxes;
+    std::vector<pt_object> h_objs;
+    DevBuf<TriPairRec> d_boxes;
+    bool boxes_dirty = true;
+    // scratch of the single-ray query entry points (kept across calls: a picking caller sends one ray per click)
+    DevBuf<float> q_o, q_d, q_t, q_x, q_n;
+    DevBuf<int32_t> q_oid, q_tid;
     // wavefront queues
     uint32_t K = 0, cap = 0;
     DevBuf<float4> q_od0[2], q_tp[2];
@@ -171,8 +210,7 @@ FrameParams make_frame(const pt_ctx *ctx, const pt_config *cfg, uint32_t idx_beg
     F.sv_x = sv[0];
     F.sv_y = sv[1];
     F.sv_z = sv[2];
-    F.debug = 0;
-    if (const char *e = getenv("PT_DEBUG")) F.debug = (uint32_t)atoi(e);
+    F.debug = ctx->tune.debug;
     return F;
 }
 
@@ -216,7 +254,7 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
     const uint64_t per_stream = c->scene.n_bvh_nodes != 0u ? 4096u : 2048u;
     uint64_t k_target = ((uint64_t)npix * spp_pass + per_stream - 1u) / per_stream;
     if (k_target < 2048u) k_target = 2048u;
-    if (const char *e = getenv("PT_STREAMS")) k_target = (uint64_t)atoll(e) > 0 ? (uint64_t)atoll(e) : k_target;  // tuning
+    if (c->tune.streams) k_target = c->tune.streams;
     uint32_t m = (uint32_t)((npix + k_target - 1) / k_target);
     if (m == 0) m = 1;
     if (m > kMaxStreamPixels) m = kMaxStreamPixels;
@@ -235,8 +273,12 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
             return rc;
     }
     int rc;
-    const bool needs_hits = c->scene.n_bvh_nodes != 0u || (cfg->flags & PT_FLAG_SEPARATE_KERNELS) ||
-                            (getenv("PT_PASS_KERNEL") && atoi(getenv("PT_PASS_KERNEL")) == 0);  // k_pass keeps hits in registers
+    // scenes without BVH meshes run a pass as one launch (k_pass), BVH scenes as k_pass_bvh unless their nodes are staged
+    // in LDS; PT_FLAG_SEPARATE_KERNELS / PT_PASS_KERNEL=0 / PT_PASS_BVH=0 keep the three-kernel form (A/B, profiling).
+    // Only that form needs the hit records: k_pass keeps hits in registers.
+    const bool bvh_ok = c->scene.n_bvh_nodes == 0u || (!(c->scene.bvh_in_lds & 1u) && c->tune.pass_bvh);
+    const bool one_kernel = bvh_ok && c->tune.pass_kernel && !(cfg->flags & PT_FLAG_SEPARATE_KERNELS);
+    const bool needs_hits = !one_kernel;
     if ((needs_hits && (rc = c->hit.ensure(slots))) || (rc = c->cnt.ensure((size_t)kLevels * K)) || (rc = c->flags.ensure(1)) ||
         (rc = c->blk_rays.ensure(K)) || (rc = c->acc.ensure(3 * (size_t)K * m)))
         return rc;
@@ -252,12 +294,6 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
 
     const uint32_t n_pass = (cfg->spp + spp_pass - 1) / spp_pass;
     const int n_depth = kMaxDepth;  // rays of depth 0..11 exist
-    // scenes without BVH meshes run a pass as one launch; PT_PASS_KERNEL=0 keeps the three-kernel form (A/B, profiling)
-    static const bool pass_kernel_off = getenv("PT_PASS_KERNEL") && atoi(getenv("PT_PASS_KERNEL")) == 0;
-    // (BVH scenes: k_pass_bvh, unless the nodes are staged in LDS - PT_BVH_LDS=1 - or PT_PASS_BVH=0)
-    static const bool pass_bvh_off = getenv("PT_PASS_BVH") && atoi(getenv("PT_PASS_BVH")) == 0;
-    const bool bvh_ok = c->scene.n_bvh_nodes == 0u || (!(c->scene.bvh_in_lds & 1u) && !pass_bvh_off);
-    const bool one_kernel = bvh_ok && !pass_kernel_off && !(cfg->flags & PT_FLAG_SEPARATE_KERNELS);
     size_t ev_i = 0;
     hipEvent_t ev_begin = get_event(c, ev_i++), ev_end = get_event(c, ev_i++);
     hipEvent_t pass_done[2] = {get_event(c, ev_i++), get_event(c, ev_i++)};
@@ -270,13 +306,28 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
     HIP_TRY(hipEventRecord(ev_begin, st));
     bool cancelled = false;
     uint32_t passes_done = 0;
+    // RenderUpdate cadence (mod.rs:965-982): the reference reports every 500 ms.  Passes are much shorter than that, so
+    // the callback is throttled to pt_config.progress_ms (0 = 500 ms, PT_PROGRESS_EVERY_PASS = every pass boundary);
+    // the cancel byte is read at EVERY pass boundary (the reference polls it every 100 ms, mod.rs:947-958).
+    const double cb_every_ms = cfg->progress_ms == PT_PROGRESS_EVERY_PASS ? 0.0 : (cfg->progress_ms ? (double)cfg->progress_ms : 500.0);
+    double cb_last_ms = now_ms();
     for (uint32_t p = 0; p < n_pass; ++p) {
         if (p >= 2) HIP_TRY(hipEventSynchronize(pass_done[p & 1]));  // keep two passes in flight
         if (cancel && *cancel) {
             cancelled = true;
             break;
         }
-        if (cb && p >= 2) cb(user, (float)(p - 1) / (float)n_pass);
+        if (cb && p >= 2) {
+            const double t_now = now_ms();
+            if (t_now - cb_last_ms >= cb_every_ms) {
+                cb_last_ms = t_now;
+                cb(user, (float)(p - 1) / (float)n_pass);
+                if (cancel && *cancel) {  // raised from inside the callback
+                    cancelled = true;
+                    break;
+                }
+            }
+        }
         const uint32_t s0 = p * spp_pass;
         const uint32_t s_here = (cfg->spp - s0) < spp_pass ? (cfg->spp - s0) : spp_pass;
         c->live_spp_issued = s0 + s_here;
@@ -370,8 +421,6 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
 
 int render_mega(pt_ctx *c, const pt_config *cfg, const FrameParams &F, hipStream_t st, const volatile uint8_t *cancel,
                 pt_progress_fn cb, void *user, pt_stats *stats) {
-    (void)cb;
-    (void)user;
     const uint64_t npix = F.npix;
     int rc;
     if ((rc = c->acc.ensure(3 * npix)) || (rc = c->total_rays.ensure(1))) return rc;
@@ -379,30 +428,67 @@ int render_mega(pt_ctx *c, const pt_config *cfg, const FrameParams &F, hipStream
     c->live_m = (uint32_t)npix;
     HIP_TRY(hipMemsetAsync(c->acc.p, 0, 3 * npix * sizeof(unsigned long long), st));
     HIP_TRY(hipMemsetAsync(c->total_rays.p, 0, sizeof(unsigned long long), st));
-    if (cancel && *cancel) {
-        set_error("cancelled");
-        return PT_CANCELLED;
-    }
-    // enough (pixel, sample-chunk) items to fill the chip several times over
+    // The frame is cut into ROUNDS: one round = every pixel of the call x round_spp consecutive samples, one launch (a
+    // lane = one pixel's samples of the round, walked one after the other).  A round is sized to about a tenth of a
+    // second of work, so the cancel byte and the progress callback are served between launches (the reference polls
+    // cancel every 100 ms, mod.rs:947-958) and every pixel holds the same number of samples at every boundary - which is
+    // what pt_ctx_snapshot and a cancelled frame resolve.  Small frames get several lanes per pixel inside a round
+    // (n_split) so that a launch still fills the chip.
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, c->device));
     const uint64_t lanes = (uint64_t)prop.multiProcessorCount * 2048u;
-    uint32_t n_chunks = 1;
-    while ((uint64_t)npix * n_chunks < 4 * lanes && n_chunks < cfg->spp) n_chunks *= 2;
-    if (n_chunks > cfg->spp) n_chunks = cfg->spp;
-    const uint32_t chunk_spp = (cfg->spp + n_chunks - 1) / n_chunks;
-    n_chunks = (cfg->spp + chunk_spp - 1) / chunk_spp;
-    const uint64_t items = npix * n_chunks;
-    uint64_t grid64 = (items + kBlock - 1) / kBlock;
-    const uint64_t max_grid = (uint64_t)prop.multiProcessorCount * 8u;
-    const uint32_t grid = (uint32_t)(grid64 < max_grid ? grid64 : max_grid);
+    const uint64_t round_budget = cfg->rays_per_pass ? cfg->rays_per_pass : (256ull << 20);  // primary samples per launch
+    uint64_t round_spp64 = round_budget / npix;
+    if (round_spp64 == 0) round_spp64 = 1;
+    if (round_spp64 > cfg->spp) round_spp64 = cfg->spp;
+    const uint32_t round_spp = (uint32_t)round_spp64;
+    uint32_t n_split = 1;  // lanes per pixel within a round
+    while ((uint64_t)npix * n_split < 4 * lanes && n_split < round_spp) n_split *= 2;
+    if (n_split > round_spp) n_split = round_spp;
+    const uint32_t n_rounds = (cfg->spp + round_spp - 1) / round_spp;
     hipEvent_t ev_begin = get_event(c, 0), ev_end = get_event(c, 1);
-    if (!ev_begin || !ev_end) {
+    hipEvent_t round_done[2] = {get_event(c, 2), get_event(c, 3)};
+    if (!ev_begin || !ev_end || !round_done[0] || !round_done[1]) {
         set_error("hipEventCreate failed");
         return PT_ERR_HIP;
     }
     HIP_TRY(hipEventRecord(ev_begin, st));
-    launch_mega(st, grid ? grid : 1u, c->scene, F, c->acc.p, chunk_spp, n_chunks, c->total_rays.p);
+    const double cb_every_ms = cfg->progress_ms == PT_PROGRESS_EVERY_PASS ? 0.0 : (cfg->progress_ms ? (double)cfg->progress_ms : 500.0);
+    double cb_last_ms = now_ms();
+    bool cancelled = false;
+    uint32_t rounds_done = 0;
+    uint64_t samples = 0;
+    for (uint32_t r = 0; r < n_rounds; ++r) {
+        if (r >= 2) HIP_TRY(hipEventSynchronize(round_done[r & 1]));  // two launches in flight
+        if (cancel && *cancel) {
+            cancelled = true;
+            break;
+        }
+        if (cb && r >= 2) {
+            const double t_now = now_ms();
+            if (t_now - cb_last_ms >= cb_every_ms) {
+                cb_last_ms = t_now;
+                cb(user, (float)(r - 1) / (float)n_rounds);
+                if (cancel && *cancel) {
+                    cancelled = true;
+                    break;
+                }
+            }
+        }
+        const uint32_t s0 = r * round_spp;
+        const uint32_t s_here = (cfg->spp - s0) < round_spp ? (cfg->spp - s0) : round_spp;
+        const uint32_t split = n_split < s_here ? n_split : s_here;
+        const uint32_t lane_spp = (s_here + split - 1) / split;
+        const uint64_t items = npix * split;
+        const uint64_t grid64 = (items + kBlock - 1) / kBlock;
+        const uint64_t max_grid = (uint64_t)prop.multiProcessorCount * 8u;
+        const uint32_t grid = (uint32_t)(grid64 < max_grid ? grid64 : max_grid);
+        launch_mega(st, grid ? grid : 1u, c->scene, F, c->acc.p, s0, s0 + s_here, lane_spp, split, c->total_rays.p);
+        HIP_TRY(hipEventRecord(round_done[r & 1], st));
+        c->live_spp_issued = s0 + s_here;
+        samples += npix * s_here;
+        ++rounds_done;
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev_end, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -412,12 +498,16 @@ int render_mega(pt_ctx *c, const pt_config *cfg, const FrameParams &F, hipStream
         stats->ray_bounces = total;
         stats->intersect_rays = 0;
         stats->intersect_launches = 0;
-        stats->passes = 1;
-        stats->samples = npix * cfg->spp;
+        stats->passes = rounds_done;
+        stats->samples = samples;
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, ev_begin, ev_end));
         stats->ms_device = ms;
         stats->ms_intersect = 0.0;
+    }
+    if (cancelled) {
+        set_error("cancelled");
+        return PT_CANCELLED;
     }
     return PT_OK;
 }
@@ -473,6 +563,7 @@ int pt_ctx_create(int device, pt_ctx **out) {
     HIP_TRY(hipSetDevice(device));
     pt_ctx *c = new pt_ctx();
     c->device = device;
+    c->tune = read_tuning();
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         set_error(std::string("hipStreamCreate: ") + hipGetErrorString(e));
@@ -497,6 +588,14 @@ void pt_ctx_destroy(pt_ctx *c) {
     c->d_mats.release();
     c->d_tshade.release();
     c->d_nodes.release();
+    c->d_boxes.release();
+    c->q_o.release();
+    c->q_d.release();
+    c->q_t.release();
+    c->q_x.release();
+    c->q_n.release();
+    c->q_oid.release();
+    c->q_tid.release();
     for (int w = 0; w < 2; ++w) {
         c->q_od0[w].release();
         c->q_od1[w].release();
@@ -556,12 +655,11 @@ int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uin
         // workgroup.  With the walks done in dense waves (k_intersect<true>) occupancy is worth more than LDS-resident
         // nodes - mesh.json: 7.7 G bounces/s staged, 8.6 G from L1/L2 - so staging is opt-in (PT_BVH_LDS=1).
         const bool ref16 = c->n_bvh_nodes < 0x8000u && fs.bvh_pair_span < 0x8000u;
-        const bool stage = ref16 && c->n_bvh_nodes <= kBvhMaxLdsNodes && getenv("PT_BVH_LDS") &&
-                           atoi(getenv("PT_BVH_LDS")) != 0;
+        const bool stage = ref16 && c->n_bvh_nodes <= kBvhMaxLdsNodes && c->tune.bvh_lds;
         c->scene.bvh_in_lds = (ref16 ? 2u : 0u) | (stage ? 1u : 0u);
     }
     c->scene.bvh_pair_base = fs.bvh_pair_base;
-    c->scene.leaf_quorum = getenv("PT_LEAF_QUORUM") ? (uint32_t)atoi(getenv("PT_LEAF_QUORUM")) : 12u;  // mesh.json: 65 (all) 11.7, 32 12.5, 16 12.8, 8 12.8, 1 11.0 G bounces/s
+    c->scene.leaf_quorum = c->tune.leaf_quorum;  // mesh.json: 65 (all) 11.7, 32 12.5, 16 12.8, 8 12.8, 1 11.0 G bounces/s
     c->scene.objs = c->d_objs.p;
     c->scene.obj_pairs = c->d_opairs.p;
     c->scene.tri_pairs = c->d_tris.p;
@@ -570,6 +668,12 @@ int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uin
     c->scene.n_objs = n_objs;
     c->scene.n_tris = n_tris;
     c->cam = *cam;
+    c->h_objs.assign(objs, objs + n_objs);
+    c->h_boxes.assign((size_t)12 * n_objs, pt_triangle{});
+    for (uint32_t i = 0; i < n_objs; ++i)
+        if (objs[i].kind == PT_MESH && objs[i].tri_count != 0u)
+            host::mesh_bounding_box(tris + objs[i].tri_offset, objs[i].tri_count, &c->h_boxes[(size_t)12 * i]);
+    c->boxes_dirty = true;
     c->has_scene = true;
     return PT_OK;
 }
@@ -737,8 +841,16 @@ int pt_ctx_render(pt_ctx *c, const pt_config *cfg, void *d_out_rgb, void *hip_st
     else
         rc = render_mega(c, cfg, F, st, cancel, cb, user, stats);
     if (rc == PT_OK || rc == PT_CANCELLED) {
-        // a cancelled frame still resolves what was accumulated (the reference also writes the partial image)
-        launch_resolve(st, c->acc.p, (float *)d_out_rgb, F.npix, cfg->spp, c->live_streams, c->live_m);
+        // A cancelled frame resolves what was accumulated by the samples per pixel that were accumulated
+        // (live_spp_issued, also reported through stats->samples): every pixel at full brightness over fewer samples -
+        // the same picture pt_ctx_snapshot gives.  (The reference's partial image has finished pixels at full spp and the
+        // rest black, mod.rs:1003-1016; a GPU pass covers every pixel, so "fewer samples everywhere" is its counterpart.)
+        // Nothing accumulated yet: all zero, as the reference's untouched `pixels` vector.
+        const uint32_t spp_done = rc == PT_OK ? cfg->spp : c->live_spp_issued;
+        if (spp_done != 0u)
+            launch_resolve(st, c->acc.p, (float *)d_out_rgb, F.npix, spp_done, c->live_streams, c->live_m);
+        else
+            HIP_TRY(hipMemsetAsync(d_out_rgb, 0, (size_t)F.npix * 3 * sizeof(float), st));
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(st));
         if (cb && rc == PT_OK) cb(user, 1.0f);
@@ -762,43 +874,107 @@ int pt_ctx_intersect(pt_ctx *c, const float *o, const float *d, uint32_t n, floa
     }
     if (n == 0) return PT_OK;
     HIP_TRY(hipSetDevice(c->device));
-    DevBuf<float> d_o, d_d, d_t, d_x, d_n;
-    DevBuf<int32_t> d_oid, d_tid;
     int rc;
-    if ((rc = d_o.ensure(3 * (size_t)n)) || (rc = d_d.ensure(3 * (size_t)n)) || (rc = d_t.ensure(n)) ||
-        (rc = d_x.ensure(3 * (size_t)n)) || (rc = d_n.ensure(3 * (size_t)n)) || (rc = d_oid.ensure(n)) ||
-        (rc = d_tid.ensure(n)))
+    if ((rc = c->q_o.ensure(3 * (size_t)n)) || (rc = c->q_d.ensure(3 * (size_t)n)) || (rc = c->q_t.ensure(n)) ||
+        (rc = c->q_x.ensure(3 * (size_t)n)) || (rc = c->q_n.ensure(3 * (size_t)n)) || (rc = c->q_oid.ensure(n)) ||
+        (rc = c->q_tid.ensure(n)))
         return rc;
-    auto cleanup = [&]() {
-        d_o.release();
-        d_d.release();
-        d_t.release();
-        d_x.release();
-        d_n.release();
-        d_oid.release();
-        d_tid.release();
-    };
-#define Q_TRY(expr)                                                       \
-    do {                                                                  \
-        hipError_t e_ = (expr);                                           \
-        if (e_ != hipSuccess) {                                           \
-            set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); \
-            cleanup();                                                    \
-            return PT_ERR_HIP;                                            \
-        }                                                                 \
-    } while (0)
-    Q_TRY(hipMemcpy(d_o.p, o, 3 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
-    Q_TRY(hipMemcpy(d_d.p, d, 3 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
-    launch_query(c->stream, c->scene, d_o.p, d_d.p, n, d_t.p, d_oid.p, d_tid.p, d_x.p, d_n.p);
-    Q_TRY(hipGetLastError());
-    Q_TRY(hipStreamSynchronize(c->stream));
-    if (t) Q_TRY(hipMemcpy(t, d_t.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
-    if (object_id) Q_TRY(hipMemcpy(object_id, d_oid.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (tri_id) Q_TRY(hipMemcpy(tri_id, d_tid.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (x) Q_TRY(hipMemcpy(x, d_x.p, 3 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
-    if (normal) Q_TRY(hipMemcpy(normal, d_n.p, 3 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
-#undef Q_TRY
-    cleanup();
+    hipStream_t st = c->stream;
+    HIP_TRY(hipMemcpyAsync(c->q_o.p, o, 3 * (size_t)n * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(c->q_d.p, d, 3 * (size_t)n * sizeof(float), hipMemcpyHostToDevice, st));
+    launch_query(st, c->scene, c->q_o.p, c->q_d.p, n, c->q_t.p, c->q_oid.p, c->q_tid.p, c->q_x.p, c->q_n.p);
+    HIP_TRY(hipGetLastError());
+    if (t) HIP_TRY(hipMemcpyAsync(t, c->q_t.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (object_id) HIP_TRY(hipMemcpyAsync(object_id, c->q_oid.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (tri_id) HIP_TRY(hipMemcpyAsync(tri_id, c->q_tid.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (x) HIP_TRY(hipMemcpyAsync(x, c->q_x.p, 3 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (normal) HIP_TRY(hipMemcpyAsync(normal, c->q_n.p, 3 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return PT_OK;
+}
+
+// device form of the bounding boxes (rebuilt after pt_ctx_set_scene / pt_ctx_set_mesh_bounds)
+static int upload_boxes(pt_ctx *c) {
+    if (!c->boxes_dirty) return PT_OK;
+    const size_t n_objs = c->h_objs.size();
+    std::vector<TriPairRec> recs(6 * (n_objs ? n_objs : 1), TriPairRec{});
+    for (size_t i = 0; i < n_objs; ++i)
+        if (c->h_objs[i].kind == PT_MESH) host::box_pair_records(&c->h_boxes[12 * i], c->h_objs[i].position, &recs[6 * i]);
+    int rc = c->d_boxes.ensure(recs.size());
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(c->d_boxes.p, recs.data(), recs.size() * sizeof(TriPairRec), hipMemcpyHostToDevice));
+    c->boxes_dirty = false;
+    return PT_OK;
+}
+
+static int bounds_query(pt_ctx *c, uint32_t mode, uint32_t object, const float *o, const float *d, uint32_t n, int32_t *hit,
+                        float *t, float *x, float *normal, int32_t *object_id) {
+    if (!c || !o || !d) {
+        set_error("NULL argument");
+        return PT_ERR_INVALID;
+    }
+    if (!c->has_scene) {
+        set_error("no scene set");
+        return PT_ERR_INVALID;
+    }
+    if (mode == 0u && object >= c->h_objs.size()) {
+        set_error("object index out of range");
+        return PT_ERR_INVALID;
+    }
+    if (n == 0) return PT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = upload_boxes(c);
+    if (rc) return rc;
+    if ((rc = c->q_o.ensure(3 * (size_t)n)) || (rc = c->q_d.ensure(3 * (size_t)n)) || (rc = c->q_t.ensure(n)) ||
+        (rc = c->q_x.ensure(3 * (size_t)n)) || (rc = c->q_n.ensure(3 * (size_t)n)) || (rc = c->q_oid.ensure(n)) ||
+        (rc = c->q_tid.ensure(n)))
+        return rc;
+    hipStream_t st = c->stream;
+    HIP_TRY(hipMemcpyAsync(c->q_o.p, o, 3 * (size_t)n * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(c->q_d.p, d, 3 * (size_t)n * sizeof(float), hipMemcpyHostToDevice, st));
+    launch_bounds(st, c->scene, c->d_boxes.p, mode, object, c->q_o.p, c->q_d.p, n, c->q_tid.p, c->q_t.p, c->q_x.p, c->q_n.p,
+                  c->q_oid.p);
+    HIP_TRY(hipGetLastError());
+    if (hit) HIP_TRY(hipMemcpyAsync(hit, c->q_tid.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (t) HIP_TRY(hipMemcpyAsync(t, c->q_t.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (x) HIP_TRY(hipMemcpyAsync(x, c->q_x.p, 3 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (normal) HIP_TRY(hipMemcpyAsync(normal, c->q_n.p, 3 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (object_id) HIP_TRY(hipMemcpyAsync(object_id, c->q_oid.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return PT_OK;
+}
+
+int pt_ctx_intersect_bounds(pt_ctx *c, uint32_t object, const float *o, const float *d, uint32_t n, int32_t *hit, float *t,
+                            float *x, float *normal) {
+    return bounds_query(c, 0u, object, o, d, n, hit, t, x, normal, nullptr);
+}
+
+int pt_ctx_orbit_point(pt_ctx *c, const float *o, const float *d, uint32_t n, int32_t *found, float *point,
+                       int32_t *object_id, float *t) {
+    return bounds_query(c, 1u, 0u, o, d, n, found, t, point, nullptr, object_id);
+}
+
+int pt_ctx_set_mesh_bounds(pt_ctx *c, uint32_t object, const pt_triangle box[12]) {
+    if (!c || !box) {
+        set_error("NULL argument");
+        return PT_ERR_INVALID;
+    }
+    if (!c->has_scene || object >= c->h_objs.size() || c->h_objs[object].kind != PT_MESH) {
+        set_error("no scene set, or object is not a mesh of it");
+        return PT_ERR_INVALID;
+    }
+    memcpy(&c->h_boxes[(size_t)12 * object], box, 12 * sizeof(pt_triangle));
+    c->boxes_dirty = true;
+    return PT_OK;
+}
+
+int pt_mesh_bounding_box(const pt_triangle *tris, uint32_t n_tris, pt_triangle out[12]) {
+    if (!tris || !out || n_tris == 0) {
+        set_error("NULL argument or empty mesh");
+        return PT_ERR_INVALID;
+    }
+    host::mesh_bounding_box(tris, n_tris, out);
     return PT_OK;
 }
 
@@ -810,7 +986,8 @@ int pt_ctx_snapshot(pt_ctx *c, void *d_out_rgb, uint32_t *spp_done) {
         return PT_ERR_INVALID;
     }
     if (c->live_npix == 0 || c->live_spp_issued == 0) {
-        set_error("no frame in progress (call from the progress callback of pt_ctx_render)");
+        set_error("no frame in progress on this context (call from the progress callback of pt_ctx_render; under "
+                  "PT_FLAG_PIPELINES the accumulators live in child contexts and no snapshot is offered)");
         return PT_ERR_INVALID;
     }
     HIP_TRY(hipSetDevice(c->device));
@@ -867,13 +1044,14 @@ static int render_band_to_host(int dev, const pt_config *cfg, const pt_camera *c
                                std::string *err) {
     uint32_t ib = 0, ie = 0;
     int rc = check_cfg(cfg, &ib, &ie);
+    if (stats) memset(stats, 0, sizeof *stats);
+    const uint32_t own = rc ? 0u : owned_pixels(cfg, ib, ie);
+    if (!rc && own == 0u) return PT_OK;  // this rank owns no chunk of the band: nothing was created yet
     pt_ctx *c = nullptr;
     if (!rc) rc = pt_ctx_create(dev, &c);
     if (!rc) rc = pt_ctx_set_scene(c, cam, objs, n_objs, tris, n_tris);
     float *d_out = nullptr;
-    const uint32_t own = rc ? 0u : owned_pixels(cfg, ib, ie);
     const size_t nfl = (size_t)own * 3;
-    if (!rc && own == 0u) return PT_OK;
     if (!rc) {
         hipError_t e = hipMalloc((void **)&d_out, nfl * sizeof(float));
         if (e != hipSuccess) {

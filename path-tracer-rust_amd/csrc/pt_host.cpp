@@ -50,6 +50,46 @@ void mesh_bounding_sphere(const pt_triangle *tris, uint32_t n, float center[3], 
     *radius = to_lo > to_hi ? to_lo : to_hi;  // max_by keeps the last of equal maxima
 }
 
+void mesh_bounding_box(const pt_triangle *tris, uint32_t n, pt_triangle out[12]) {
+    const float inf = std::numeric_limits<float>::infinity();
+    vec3 lo = mk(inf, inf, inf), hi = mk(-inf, -inf, -inf);
+    for (uint32_t i = 0; i < n; ++i) {
+        const float *corners[3] = {tris[i].a, tris[i].b, tris[i].c};
+        for (const float *v : corners) {
+            lo.x = v[0] < lo.x ? v[0] : lo.x;
+            lo.y = v[1] < lo.y ? v[1] : lo.y;
+            lo.z = v[2] < lo.z ? v[2] : lo.z;
+            hi.x = v[0] > hi.x ? v[0] : hi.x;
+            hi.y = v[1] > hi.y ? v[1] : hi.y;
+            hi.z = v[2] > hi.z ? v[2] : hi.z;
+        }
+    }
+    // bounding_box_to_triangles, mod.rs:501-536: vertex and index tables as written there
+    const vec3 vtx[8] = {mk(lo.x, lo.y, lo.z), mk(hi.x, lo.y, lo.z), mk(hi.x, hi.y, lo.z), mk(lo.x, hi.y, lo.z),
+                         mk(lo.x, lo.y, hi.z), mk(hi.x, lo.y, hi.z), mk(hi.x, hi.y, hi.z), mk(lo.x, hi.y, hi.z)};
+    static const int idx[12][3] = {{0, 1, 2}, {0, 2, 3}, {4, 6, 5}, {4, 7, 6}, {0, 4, 5}, {0, 5, 1},
+                                   {3, 2, 6}, {3, 6, 7}, {1, 5, 6}, {1, 6, 2}, {0, 3, 7}, {0, 7, 4}};
+    for (int k = 0; k < 12; ++k) {
+        st(out[k].a, vtx[idx[k][0]]);
+        st(out[k].b, vtx[idx[k][1]]);
+        st(out[k].c, vtx[idx[k][2]]);
+    }
+}
+
+void box_pair_records(const pt_triangle box[12], const float position[3], TriPairRec out[6]) {
+    const vec3 pos = ld(position);
+    for (int k = 0; k < 12; ++k) {
+        const vec3 a = ld(box[k].a) + pos, b = ld(box[k].b) + pos, c = ld(box[k].c) + pos;
+        const vec3 e1 = b - a, e2 = c - a;
+        TriPairRec &r = out[k / 2];
+        const int hf = k & 1;
+        r.ax[hf] = a.x, r.ay[hf] = a.y, r.az[hf] = a.z;
+        r.e1x[hf] = e1.x, r.e1y[hf] = e1.y, r.e1z[hf] = e1.z;
+        r.e2x[hf] = e2.x, r.e2y[hf] = e2.y, r.e2z[hf] = e2.z;
+        r.id[hf] = (uint32_t)k;
+    }
+}
+
 namespace {
 
 struct BuildTri {

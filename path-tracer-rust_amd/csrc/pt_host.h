@@ -28,6 +28,11 @@ struct FlatScene {
 void camera_basis(const pt_camera &cam, float lens_center[3], float su[3], float sv[3]);
 // Mesh::new bounding sphere — src/render/mod.rs:450-499
 void mesh_bounding_sphere(const pt_triangle *tris, uint32_t n, float center[3], float *radius);
+// Mesh::new's bounding_box: bounding_box_to_triangles over the AABB of the (object-local) triangles — src/render/mod.rs:452-476,501-536
+void mesh_bounding_box(const pt_triangle *tris, uint32_t n, pt_triangle out[12]);
+// the 12 triangles of one object's bounding box as 6 pair records in list order (world space: Triangle::transformed,
+// mod.rs:546-552, then the edge subtractions of mod.rs:560-561), ids 0..11 — what SceneObjectData::intersect_bounds scans
+void box_pair_records(const pt_triangle box[12], const float position[3], TriPairRec out[6]);
 // validate + flatten (see pt_device.h for the record layouts); false + message on malformed input
 // `cam` only widens the distance bound that sizes the BVH box padding (ray origins include the lens centre)
 bool flatten_scene(const pt_camera &cam, const pt_object *objs, uint32_t n_objs, const pt_triangle *tris,

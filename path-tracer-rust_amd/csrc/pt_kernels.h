@@ -39,10 +39,14 @@ void launch_scatter_chunks(hipStream_t st, const float *src, float *dst, uint32_
 // acc is stream-major: pixel p = slot (p % n_streams) * m + p / n_streams of each colour plane (megakernel: 1, npix)
 void launch_resolve(hipStream_t st, const unsigned long long *acc, float *out, uint32_t npix, uint32_t spp,
                     uint32_t n_streams, uint32_t m);
+// one round of the megakernel: samples [s_begin, s_end) of every pixel, n_split lanes of lane_spp samples per pixel
 void launch_mega(hipStream_t st, uint32_t grid, const DevScene &S, const FrameParams &F, unsigned long long *acc,
-                 uint32_t chunk_spp, uint32_t n_chunks, unsigned long long *total_rays);
+                 uint32_t s_begin, uint32_t s_end, uint32_t lane_spp, uint32_t n_split, unsigned long long *total_rays);
 void launch_query(hipStream_t st, const DevScene &S, const float *o, const float *d, uint32_t n, float *t,
                   int32_t *object_id, int32_t *tri_id, float *x, float *nrm);
+// mode 0: intersect_bounds of one object; mode 1: get_orbit_point (see k_bounds)
+void launch_bounds(hipStream_t st, const DevScene &S, const TriPairRec *boxes, uint32_t mode, uint32_t object, const float *o,
+                   const float *d, uint32_t n, int32_t *hit, float *t, float *x, float *nrm, int32_t *object_id);
 void launch_numerics(hipStream_t st, const float *in, uint32_t n, float *out_sin, float *out_cos, float *out_sqrt,
                      float *out_rcp, uint32_t *out_philox);
 

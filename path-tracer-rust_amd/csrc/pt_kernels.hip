@@ -671,21 +671,24 @@ __global__ __launch_bounds__(kBlock) void k_scatter_chunks(const float *__restri
 // other and each loop trip advances every live path of the wave by one bounce, so the intersect and
 // shade code is executed by (nearly) full waves whatever the depths of the individual paths.
 // The refract split (mod.rs:775-786) pushes the transmitted ray on a two-entry stack in registers.
+// One launch = one ROUND: the samples [s_begin, s_end) of every pixel of the call; item = (pixel, part of the round):
+// part k of `n_split` walks the samples s_begin + k*lane_spp ... (< s_end).
 template <bool BVH>
 __global__ __launch_bounds__(kBlock) void k_mega(DevScene S, FrameParams F, unsigned long long *__restrict__ acc,
-                                                 uint32_t chunk_spp, uint32_t n_chunks,
+                                                 uint32_t s_begin, uint32_t s_end, uint32_t lane_spp, uint32_t n_split,
                                                  unsigned long long *__restrict__ total_rays) {
-    const uint64_t items = (uint64_t)F.npix * n_chunks;
+    const uint64_t items = (uint64_t)F.npix * n_split;
     unsigned long long rays = 0;
     if (BVH) stage_bvh(S, dyn_lds);
     for (uint64_t first = (uint64_t)blockIdx.x * kBlock; first < items; first += (uint64_t)gridDim.x * kBlock) {
         const uint64_t item = first + threadIdx.x;
         const bool lane_valid = item < items;
         const uint32_t pl = lane_valid ? (uint32_t)(item % F.npix) : 0u;
-        const uint32_t chunk = lane_valid ? (uint32_t)(item / F.npix) : 0u;
-        uint32_t s = chunk * chunk_spp;
-        const uint32_t s_lim = s + chunk_spp;
-        const uint32_t s_end = lane_valid ? (s_lim < F.spp ? s_lim : F.spp) : s;
+        const uint32_t part = lane_valid ? (uint32_t)(item / F.npix) : 0u;
+        uint32_t s = s_begin + part * lane_spp;
+        const uint32_t s_lim = s + lane_spp;
+        const uint32_t s_stop = lane_valid ? (s_lim < s_end ? s_lim : s_end) : s;
+        if (s > s_stop) s = s_stop;
         uint64_t ar = 0, ag = 0, ab = 0;
         PathRay cur, st0, st1;
         cur.o = cur.d = cur.thr = mk(0.0f, 0.0f, 0.0f);
@@ -705,7 +708,7 @@ __global__ __launch_bounds__(kBlock) void k_mega(DevScene S, FrameParams F, unsi
                     cur = st0;
                     sp = 0;
                     active = true;
-                } else if (s < s_end) {
+                } else if (s < s_stop) {
                     cur = primary_ray(F, global_pixel(F, pl), s);
                     ++s;
                     active = true;
@@ -797,6 +800,113 @@ __global__ __launch_bounds__(kBlock) void k_query(DevScene S, const float *__res
     }
 }
 
+// intersect_bounds / get_orbit_point (picking callers next to the path: mod.rs:282-290, viewport_tab.rs:401-431).
+// One lane = one ray, plain per-lane loops: these queries come one ray at a time.  `boxes` holds 6 pair records per
+// object (box_pair_records; ignored for spheres).
+__device__ __forceinline__ bool sphere_hit(const ObjRec &g, vec3 o, vec3 d, float *t_out) {  // intersect_sphere, mod.rs:412-427
+    const vec3 op = mk(g.cx, g.cy, g.cz) - o;
+    const float b = dot(op, d);
+    const float det = (b * b - dot(op, op)) + g.rr;
+    if (det < 0.0f) return false;
+    const float sq = f_sqrt(det);
+    const float t0 = b - sq, t1 = b + sq;
+    if (t0 >= 1e-4f) {
+        *t_out = t0;
+        return true;
+    }
+    if (t1 >= 1e-4f) {
+        *t_out = t1;
+        return true;
+    }
+    return false;
+}
+// Triangle::intersect over `count` pair records in list order (first of equal distances wins, mod.rs:598)
+__device__ __forceinline__ bool scan_pairs(const TriPairRec *recs, uint32_t count, vec3 o, vec3 d, float *t_out, int32_t *id_out) {
+    const f32x2 ox2 = splat2(o.x), oy2 = splat2(o.y), oz2 = splat2(o.z);
+    const f32x2 dx2 = splat2(d.x), dy2 = splat2(d.y), dz2 = splat2(d.z);
+    float mt = __builtin_inff();
+    int32_t mid = -1;
+    for (uint32_t p = 0; p < count; ++p) test_pair<false>(recs[p], ox2, oy2, oz2, dx2, dy2, dz2, mt, mid);
+    *t_out = mt;
+    *id_out = mid;
+    return mid >= 0;
+}
+// normal of the triangle `id` found by scan_pairs: va_vb.cross(va_vc).normalize() (mod.rs:605)
+__device__ __forceinline__ vec3 pair_normal(const TriPairRec *recs, uint32_t count, int32_t id) {
+    for (uint32_t p = 0; p < count; ++p)
+        for (int hf = 0; hf < 2; ++hf)
+            if ((int32_t)recs[p].id[hf] == id)
+                return normalize(cross(mk(recs[p].e1x[hf], recs[p].e1y[hf], recs[p].e1z[hf]),
+                                       mk(recs[p].e2x[hf], recs[p].e2y[hf], recs[p].e2z[hf])));
+    return mk(0.0f, 0.0f, 0.0f);
+}
+
+// mode 0: SceneObjectData::intersect_bounds of object `object` -> hit, t, x, normal
+// mode 1: get_orbit_point over the whole scene -> hit (found), t, x (the point), object_id
+__global__ __launch_bounds__(kBlock) void k_bounds(DevScene S, const TriPairRec *__restrict__ boxes, uint32_t mode,
+                                                   uint32_t object, const float *__restrict__ o,
+                                                   const float *__restrict__ d, uint32_t n, int32_t *__restrict__ hit,
+                                                   float *__restrict__ t, float *__restrict__ x,
+                                                   float *__restrict__ nrm, int32_t *__restrict__ object_id) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const vec3 ro = mk(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
+        const vec3 rd = mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+        bool have = false;
+        float best_t = 0.0f;
+        vec3 best_n = mk(0.0f, 0.0f, 0.0f);
+        int32_t best_obj = -1;
+        const int32_t k_first = mode == 0u ? (int32_t)object : (int32_t)S.n_objs - 1;
+        const int32_t k_last = mode == 0u ? (int32_t)object : 0;
+        for (int32_t k = k_first; k >= k_last; --k) {  // reverse order, strict '<' (viewport_tab.rs:404,419)
+            const ObjRec g = S.objs[k];
+            const MatRec m = S.mats[k];
+            float tb = 0.0f;
+            vec3 nb = mk(0.0f, 0.0f, 0.0f);
+            bool hb;
+            if (g.kind == kKindSphere) {
+                hb = sphere_hit(g, ro, rd, &tb);
+                if (hb) nb = normalize((ro + rd * tb) - mk(m.px, m.py, m.pz));
+            } else {
+                int32_t bid;
+                hb = scan_pairs(boxes + 6u * (uint32_t)k, 6u, ro, rd, &tb, &bid);
+                if (hb) nb = pair_normal(boxes + 6u * (uint32_t)k, 6u, bid);
+            }
+            if (!hb) continue;
+            float tn = tb;
+            vec3 nn = nb;
+            if (mode == 1u && g.kind == kKindMesh) {  // the object's own hit if it has one, else the bounds hit
+                float tg, to;
+                int32_t tid;
+                if (sphere_hit(g, ro, rd, &tg) && scan_pairs(S.tri_pairs + g.pair_begin, g.pair_count, ro, rd, &to, &tid)) {
+                    tn = to;
+                    const TriShade ts = S.tri_shade[tid];
+                    nn = mk(ts.nx, ts.ny, ts.nz);
+                }
+            }
+            if (!have || tn < best_t) {
+                have = true;
+                best_t = tn;
+                best_n = nn;
+                best_obj = k;
+            }
+        }
+        const vec3 bx = have ? ro + rd * best_t : mk(0.0f, 0.0f, 0.0f);
+        if (hit) hit[i] = have ? 1 : 0;
+        if (t) t[i] = have ? best_t : 0.0f;
+        if (object_id) object_id[i] = best_obj;
+        if (x) {
+            x[3 * i] = bx.x;
+            x[3 * i + 1] = bx.y;
+            x[3 * i + 2] = bx.z;
+        }
+        if (nrm) {
+            nrm[3 * i] = best_n.x;
+            nrm[3 * i + 1] = best_n.y;
+            nrm[3 * i + 2] = best_n.z;
+        }
+    }
+}
+
 // numerics self-check kernel: the device evaluates the contract functions on given inputs so that the
 // tests can compare them bit for bit with the oracle's host evaluation.
 __global__ void k_numerics(const float *__restrict__ in, uint32_t n, float *__restrict__ out_sin,
@@ -880,12 +990,13 @@ void launch_resolve(hipStream_t st, const unsigned long long *acc, float *out, u
                        n_streams, m);
 }
 void launch_mega(hipStream_t st, uint32_t grid, const DevScene &S, const FrameParams &F, unsigned long long *acc,
-                 uint32_t chunk_spp, uint32_t n_chunks, unsigned long long *total_rays) {
+                 uint32_t s_begin, uint32_t s_end, uint32_t lane_spp, uint32_t n_split, unsigned long long *total_rays) {
     if (S.n_bvh_nodes != 0u)
-        hipLaunchKernelGGL(k_mega<true>, dim3(grid), dim3(kBlock), bvh_lds_bytes(S, kBlock), st, S, F, acc, chunk_spp,
-                           n_chunks, total_rays);
+        hipLaunchKernelGGL(k_mega<true>, dim3(grid), dim3(kBlock), bvh_lds_bytes(S, kBlock), st, S, F, acc, s_begin, s_end,
+                           lane_spp, n_split, total_rays);
     else
-        hipLaunchKernelGGL(k_mega<false>, dim3(grid), dim3(kBlock), 0, st, S, F, acc, chunk_spp, n_chunks, total_rays);
+        hipLaunchKernelGGL(k_mega<false>, dim3(grid), dim3(kBlock), 0, st, S, F, acc, s_begin, s_end, lane_spp, n_split,
+                           total_rays);
 }
 void launch_query(hipStream_t st, const DevScene &S, const float *o, const float *d, uint32_t n, float *t,
                   int32_t *object_id, int32_t *tri_id, float *x, float *nrm) {
@@ -893,6 +1004,13 @@ void launch_query(hipStream_t st, const DevScene &S, const float *o, const float
     if (grid > 4096u) grid = 4096u;
     if (grid == 0u) grid = 1u;
     hipLaunchKernelGGL(k_query, dim3(grid), dim3(kBlock), bvh_lds_bytes(S, kBlock), st, S, o, d, n, t, object_id, tri_id, x, nrm);
+}
+void launch_bounds(hipStream_t st, const DevScene &S, const TriPairRec *boxes, uint32_t mode, uint32_t object, const float *o,
+                   const float *d, uint32_t n, int32_t *hit, float *t, float *x, float *nrm, int32_t *object_id) {
+    uint32_t grid = (n + kBlock - 1) / kBlock;
+    if (grid > 4096u) grid = 4096u;
+    if (grid == 0u) grid = 1u;
+    hipLaunchKernelGGL(k_bounds, dim3(grid), dim3(kBlock), 0, st, S, boxes, mode, object, o, d, n, hit, t, x, nrm, object_id);
 }
 void launch_numerics(hipStream_t st, const float *in, uint32_t n, float *out_sin, float *out_cos, float *out_sqrt,
                      float *out_rcp, uint32_t *out_philox) {

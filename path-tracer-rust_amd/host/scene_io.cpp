@@ -1077,6 +1077,17 @@ const pt_triangle *pt_scene_triangles(const pt_scene *s, uint32_t *n) {
     if (n) *n = s ? (uint32_t)s->triangles.size() : 0;
     return s ? s->triangles.data() : nullptr;
 }
+const pt_triangle *pt_scene_bounding_box(const pt_scene *cs, uint32_t object) {
+    pt_scene *s = const_cast<pt_scene *>(cs);  // the computed box of a MeshFile / API mesh is cached in its descriptor
+    if (!s || object >= s->objects.size() || s->objects[object].kind != PT_MESH) return nullptr;
+    if (s->desc.size() < s->objects.size()) s->desc.resize(s->objects.size());
+    ObjDesc &d = s->desc[object];
+    if (d.bounding_box.size() != 12) {
+        const pt_object &o = s->objects[object];
+        d.bounding_box = box_triangles(s->triangles.data() + o.tri_offset, o.tri_count);
+    }
+    return d.bounding_box.data();
+}
 
 // SipHash-c-d (Aumasson & Bernstein), little-endian message words, 64-bit tag
 uint64_t pt_siphash(uint32_t c_rounds, uint32_t d_rounds, uint64_t k0, uint64_t k1, const uint8_t *data, size_t len) {

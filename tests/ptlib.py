@@ -38,7 +38,7 @@ class PtConfig(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("spp", C.c_uint32), ("backend", C.c_uint32),
                 ("seed", C.c_uint64), ("idx_begin", C.c_uint32), ("idx_end", C.c_uint32),
                 ("rays_per_pass", C.c_uint32), ("flags", C.c_uint32), ("chunk_pixels", C.c_uint32),
-                ("chunk_first", C.c_uint32), ("chunk_step", C.c_uint32), ("reserved", C.c_uint32)]
+                ("chunk_first", C.c_uint32), ("chunk_step", C.c_uint32), ("progress_ms", C.c_uint32)]
 
 
 class PtStats(C.Structure):
@@ -66,6 +66,8 @@ PT_SPHERE, PT_MESH = 0, 1
 REFLECT = {"Diffuse": 0, "Specular": 1, "Refract": 2}
 BACKEND_WAVEFRONT, BACKEND_MEGAKERNEL = 0, 1
 FLAG_NO_BVH = 1
+PROGRESS_EVERY_PASS = 0xffffffff
+PT_CANCELLED = -4
 
 fp = C.POINTER(C.c_float)
 i32p = C.POINTER(C.c_int32)
@@ -185,6 +187,17 @@ def product():
     L.pt_host_sincos.restype = None
     L.pt_ctx_numerics_probe.argtypes = [C.c_void_p, fp, C.c_uint32, fp, fp, fp, fp, u32p]
     L.pt_ctx_intersect.argtypes = [C.c_void_p, fp, fp, C.c_uint32, fp, i32p, i32p, fp, fp]
+    L.pt_ctx_intersect_bounds.argtypes = [C.c_void_p, C.c_uint32, fp, fp, C.c_uint32, i32p, fp, fp, fp]
+    L.pt_ctx_orbit_point.argtypes = [C.c_void_p, fp, fp, C.c_uint32, i32p, fp, i32p, fp]
+    L.pt_ctx_set_mesh_bounds.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(PtTriangle)]
+    L.pt_mesh_bounding_box.argtypes = [C.POINTER(PtTriangle), C.c_uint32, C.POINTER(PtTriangle)]
+    L.pt_scene_bounding_box.argtypes = [C.c_void_p, C.c_uint32]
+    L.pt_scene_bounding_box.restype = C.POINTER(PtTriangle)
+    L.pt_comm_unique_id.argtypes = [C.c_char_p]
+    L.pt_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]
+    L.pt_comm_destroy.argtypes = [C.c_void_p]
+    L.pt_comm_destroy.restype = None
+    L.pt_comm_gather_frame.argtypes = [C.c_void_p, C.POINTER(PtConfig), C.c_void_p, C.c_void_p, C.c_void_p]
     L.pt_render.argtypes = [C.POINTER(PtConfig), C.POINTER(PtCamera), C.POINTER(PtObject), C.c_uint32,
                             C.POINTER(PtTriangle), C.c_uint32, fp, C.c_void_p, C.c_void_p, C.c_void_p,
                             C.POINTER(PtStats)]

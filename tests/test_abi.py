@@ -25,13 +25,15 @@ def declared_functions():
 
 def test_every_declared_symbol_is_exported():
     names = declared_functions()
-    assert len(names) >= 25
+    assert len(names) >= 45
+    for must in ("pt_ctx_intersect_bounds", "pt_ctx_orbit_point", "pt_comm_gather_frame", "pt_scene_bounding_box"):
+        assert must in names
     for n in names:
         assert hasattr(L, n), "libptrace_hip.so does not export " + n
 
 
 def test_version_and_struct_sizes():
-    assert L.pt_abi_version() == 2
+    assert L.pt_abi_version() == 3
     assert b"gfx950" in L.pt_version()
     # POD layout the Rust/cgo/ctypes side must match (include/ptrace.h)
     assert C.sizeof(ptlib.PtCamera) == 36
@@ -156,3 +158,38 @@ def test_siphash_pinned_and_image_hash():
         img = rng.uniform(0, 1, size=n).astype(np.float32)
         assert L.pt_image_hash(_np_f(img), n) == O.pto_image_hash(_np_f(img), n)
         assert L.pt_image_hash(_np_f(img), n) == L.pt_siphash(1, 3, 0, 0, img.tobytes(), 4 * n)
+
+
+def test_mesh_bounding_box_matches_oracle_and_stored_boxes():
+    """pt_mesh_bounding_box == the oracle's Mesh::new box (mod.rs:452-476, 501-536); pt_scene_bounding_box returns the
+    boxes the reference serialised into cornell.json (inline meshes) and Mesh::new's for a MeshFile object."""
+    for sid in ("cornell", "mesh"):
+        sc = ptlib.load_scene_py(ptlib.scene_path(sid))
+        want = ptlib.oracle_boxes(sc)
+        h = C.c_void_p()
+        assert L.pt_scene_load(ptlib.scene_path(sid).encode(), ptlib.ROOT.encode(), C.byref(h)) == 0, L.pt_last_error()
+        for i in range(sc.n_objs):
+            o = sc.objs[i]
+            stored = L.pt_scene_bounding_box(h, i)
+            if o.kind != ptlib.PT_MESH:
+                assert not stored
+                continue
+            arr = (ptlib.PtTriangle * o.tri_count)(*[sc.tris[o.tri_offset + k] for k in range(o.tri_count)])
+            got = (ptlib.PtTriangle * 12)()
+            assert L.pt_mesh_bounding_box(arr, o.tri_count, got) == 0
+            for k in range(12):
+                for key in "abc":
+                    assert list(getattr(got[k], key)) == list(getattr(want[12 * i + k], key)), (sid, i, k, key)
+                    assert list(getattr(stored[k], key)) == list(getattr(want[12 * i + k], key)), (sid, i, k, key)
+        L.pt_scene_free(h)
+
+
+def test_comm_entry_points_fail_cleanly_without_a_gpu():
+    """pt_comm_* (RCCL behind the C ABI): argument checks and the no-device answer; no collective is attempted here."""
+    assert L.pt_comm_create(0, 0, 1, None, None) == -1
+    if L.pt_device_count() > 0:
+        pytest.skip("a GPU is present")
+    comm = C.c_void_p()
+    ident = C.create_string_buffer(128)
+    assert L.pt_comm_create(0, 0, 1, ident, C.byref(comm)) == -2
+    assert not comm.value
