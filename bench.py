@@ -3,9 +3,13 @@
 
 One step = one whole frame of BASELINE.json's metric workload (scenes/cornell.json, 1024x768, 4096 spp by
 default) rendered by the wavefront HIP pipeline through the C ABI, the scene already resident in HBM.
-With N ranks (one process per GPU, launched by torch.distributed.run) rank r renders image rows r, r+N, ...,
-and one RCCL all-gather assembles the image: total work is fixed, so scaling is "strong".
-value = ray bounces of all ranks / max-over-ranks time.
+With N ranks (one process per GPU) rank r renders image rows r, r+N, ..., and one RCCL all-gather assembles the image:
+total work is fixed, so scaling is "strong".  value = ray bounces of all ranks / max-over-ranks time.
+`python bench.py --gpus N` starts the N ranks itself (a child `python -m torch.distributed.run --nproc-per-node N bench.py
+...`; the parent never touches a GPU and only relays the children's output and return code); launched under
+torch.distributed.run (WORLD_SIZE set) it is one of the ranks.  --gather torch (default): the collective is
+torch.distributed's all_gather_into_tensor (backend "nccl" = RCCL); --gather abi: the C ABI's own pt_comm_gather_frame
+(ncclAllGather + un-permute kernel inside libptrace_hip.so), torch.distributed only carrying the 128-byte id.
 
 The JSON line also carries
   roofline      the dominant kernel, timed live with HIP events around each of its launches in the timed region,
@@ -101,7 +105,27 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=128)  # ~15-20 s of CPU work on 16 host cores
+    ap.add_argument("--gather", default="torch", choices=["torch", "abi"],
+                    help="who runs the framebuffer all-gather: torch.distributed (RCCL) or the C ABI's pt_comm_gather_frame")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="with one rank: initialise the process group / communicator and run the all-gather anyway "
+                         "(checks the RCCL path on a one-GPU box)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Not under a launcher: start the ranks as children.  This process has not touched the GPU (no torch.cuda call,
+        # no HIP call) and never will: it relays the children's JSON line and return code.
+        import socket
+        import subprocess
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
     import torch
 
@@ -110,27 +134,48 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, world, args.gpus))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: the launcher started a different number of ranks" % (args.gpus, world))
+    dist_backend = os.environ.get("PT_BENCH_DIST_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()  # counting devices does not initialise the GPU
+    if n_dev == 0:
+        raise SystemExit("rank %d: bench.py needs a GPU: the product has no CPU path" % rank)
+    if dist_backend == "nccl" and local_rank >= n_dev:
+        raise SystemExit("rank %d: --gpus %d needs %d devices (one rank per GPU over RCCL), this box has %d"
+                         % (rank, args.gpus, args.gpus, n_dev))
     # PT_BENCH_DIST_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share devices and
     # the band gather goes through host memory); the measured configuration is one rank per GPU over RCCL ("nccl")
-    dist_backend = os.environ.get("PT_BENCH_DIST_BACKEND", "nccl")
-    n_dev = torch.cuda.device_count()
     dev_index = local_rank if dist_backend == "nccl" else local_rank % max(1, n_dev)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    use_collective = world > 1 or args.force_collective
+    abi_gather = args.gather == "abi" and use_collective
+    if use_collective:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if dist_backend == "nccl":
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        if abi_gather:
+            # the data plane is libptrace_hip's own RCCL communicator; torch.distributed (gloo) only carries the id,
+            # the barrier and the scalar reductions of the timing
+            dist.init_process_group(backend="gloo")
+        elif dist_backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=dist_backend)
-    coll_dev = dev if dist_backend == "nccl" else torch.device("cpu")
+    coll_dev = dev if (dist_backend == "nccl" and not abi_gather) else torch.device("cpu")
+    comm = None
+    if abi_gather:
+        # one RCCL in the process: torch has loaded its bundled copy (and its HIP runtime, which libptrace_hip.so then
+        # shares by soname), so the C ABI is pointed at that copy rather than at /opt/rocm's
+        torch_rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if os.path.exists(torch_rccl):
+            os.environ.setdefault("PT_RCCL_LIB", torch_rccl)
+        ident = [pkg.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)
+        comm = pkg.Comm(dev_index, rank, world, ident[0])
 
     W, H, spp = args.width, args.height, args.spp
     npix = W * H
@@ -143,6 +188,7 @@ def main():
     counts = pkg.chunk_counts(npix, world, chunk)
     chunks = (chunk, rank, world) if world > 1 else None
     local = torch.zeros((counts[rank], 3), dtype=torch.float32, device=dev)
+    frame = torch.zeros((npix, 3), dtype=torch.float32, device=dev) if abi_gather else None
 
     def barrier():
         if dist is not None:
@@ -153,7 +199,12 @@ def main():
         ctx.set_profiling(profile)
         st = ctx.render(local.data_ptr(), W, H, spp, seed=args.seed, backend=backend, chunks=chunks,
                         rays_per_pass=args.rays_per_pass, pipelines=pipelines, separate_kernels=separate)
-        full = pkg.gather_chunks(local if dist_backend == "nccl" else local.cpu(), npix, rank, world, chunk, dist)
+        if abi_gather:
+            comm.gather_frame(local.data_ptr(), frame.data_ptr(), W, H, chunk)
+            full = frame
+        else:
+            full = pkg.gather_chunks(local if dist_backend == "nccl" else local.cpu(), npix, rank, world, chunk, dist,
+                                     force_collective=args.force_collective)
         return st, full
 
     def timed(backend, steps, warmup, profile, pipelines=1, separate=False):
@@ -205,11 +256,15 @@ def main():
                         % (args.scene, W, H, spp, args.backend, world,
                            " (interleaved rows) + one RCCL all-gather of the framebuffer" if world > 1 else ""),
             "backend": args.backend,
-            "collective": ("RCCL all_gather_into_tensor" if dist_backend == "nccl" else dist_backend + " (rehearsal)")
-                          if world > 1 else None,
+            "collective": (("pt_comm_gather_frame (C ABI: ncclAllGather + un-permute kernel)" if abi_gather else
+                            "RCCL all_gather_into_tensor" if dist_backend == "nccl" else dist_backend + " (rehearsal)")
+                           if use_collective else None),
             "partition": "rows interleaved over ranks (chunk = %d pixels)" % chunk if world > 1 else "whole frame",
             "width": W, "height": H, "spp": spp, "seed": args.seed,
             "ray_bounces_per_frame": main_run["bounces"] // max(1, args.steps),
+            # Image.hash of the assembled frame (mod.rs:916-926: SipHash-1-3 of the f32 bits): equal across rank counts,
+            # backends and gather paths
+            "image_hash": "%016x" % pkg.image_hash(main_run["image"]),
         },
     }
     if args.backend == "wavefront" and main_run["isect_ms"] > 0:
@@ -296,6 +351,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline(W, H, args.seed, args.cpu_spp)
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -89,6 +89,13 @@ def lib():
     L.pt_scene_triangles.restype = C.POINTER(pt_triangle)
     L.pt_write_ppm.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p,
                                C.c_uint64]
+    L.pt_image_hash.argtypes = [C.POINTER(C.c_float), C.c_size_t]
+    L.pt_image_hash.restype = C.c_uint64
+    L.pt_comm_unique_id.argtypes = [C.c_char_p]
+    L.pt_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]
+    L.pt_comm_destroy.argtypes = [C.c_void_p]
+    L.pt_comm_destroy.restype = None
+    L.pt_comm_gather_frame.argtypes = [C.c_void_p, C.POINTER(pt_config), C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -166,6 +173,51 @@ class Context:
             pass
 
 
+class Comm:
+    """pt_comm: the RCCL framebuffer gather behind the C ABI (include/ptrace.h).  `unique_id()` on rank 0, the 128
+    bytes carried to the other ranks by the host's own means (bench.py: the torch.distributed store), then every rank
+    constructs Comm(device, rank, world, id) collectively."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(Comm.ID_BYTES)
+        _check(lib().pt_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, device, rank, world, ident):
+        self._h = C.c_void_p()
+        self.rank, self.world = rank, world
+        _check(lib().pt_comm_create(device, rank, world, C.create_string_buffer(ident, Comm.ID_BYTES), C.byref(self._h)))
+
+    def gather_frame(self, local_ptr, frame_ptr, width, height, chunk_pixels, band=None, stream=None):
+        """Every rank gets the whole band in device memory at frame_ptr (one ncclAllGather + the un-permute kernel)."""
+        cfg = pt_config(width, height, 1, 0, 0, 0, 0, 0, 0)
+        if band is not None:
+            cfg.idx_begin, cfg.idx_end = band
+        cfg.chunk_pixels = chunk_pixels
+        _check(lib().pt_comm_gather_frame(self._h, C.byref(cfg), C.c_void_p(local_ptr), C.c_void_p(frame_ptr),
+                                          C.c_void_p(stream or 0)))
+
+    def close(self):
+        if self._h:
+            lib().pt_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def image_hash(frame):
+    """Image.hash (mod.rs:916-926) of a [pixels, 3] float32 torch tensor (any device): pt_image_hash over its bits."""
+    host = frame.detach().to("cpu").contiguous()
+    return int(lib().pt_image_hash(C.cast(host.data_ptr(), C.POINTER(C.c_float)), host.numel()))
+
+
 def band_for_rank(npix, rank, world):
     """Contiguous band of framebuffer indices for `rank` of `world`: [rank*npix/world, (rank+1)*npix/world).
     idx = (H-1-y)*W + x is row-major (mod.rs:805-806), so a band is one contiguous slice of the image."""
@@ -189,9 +241,9 @@ def chunk_counts(npix, world, chunk_pixels):
 
 
 def chunk_owner_map(npix, world, chunk_pixels):
-    """Interleaved partition: chunk c (chunk_pixels consecutive framebuffer indices) belongs to rank c % world.
-    Returns (counts, index) where counts[r] = pixels of rank r and index[r] = the framebuffer indices of rank r's
-    pixels in the order pt_ctx_render writes them (its chunks back to back)."""
+    """Interleaved partition spelled out: chunk c (chunk_pixels consecutive framebuffer indices) belongs to rank
+    c % world.  Returns (counts, index) with index[r] = the framebuffer indices of rank r's pixels in the order
+    pt_ctx_render writes them.  O(npix * world): the explicit form the tests hold the arithmetic against."""
     import torch
     idx = torch.arange(npix, dtype=torch.int64)
     owner = (idx // chunk_pixels) % world
@@ -199,15 +251,18 @@ def chunk_owner_map(npix, world, chunk_pixels):
     return [int(i.numel()) for i in index], index
 
 
-def gather_chunks(local, npix, rank, world, chunk_pixels, dist=None):
+def gather_chunks(local, npix, rank, world, chunk_pixels, dist=None, force_collective=False):
     """One all-gather of the per-rank chunk buffers ([owned pixels, 3]) and the permutation back to framebuffer
-    order.  Equal shares (npix a multiple of world*chunk_pixels) use all_gather_into_tensor + a strided view copy."""
+    order.  Equal shares (npix a multiple of world*chunk_pixels) use all_gather_into_tensor + a strided view copy;
+    ragged shares pad every rank to whole chunks and copy rank r's chunks to the frame's chunks r, r+world, ...
+    (one strided copy per rank: O(npix) bytes, no index tensors).  world == 1 is the identity unless
+    force_collective asks for the collective anyway (hardware check of the RCCL path on a one-GPU box)."""
     import torch
-    if world == 1:
+    if world == 1 and not force_collective:
         return local
     if dist is None:
         import torch.distributed as dist
-    counts = chunk_counts(npix, world, chunk_pixels)  # (the index lists cost O(npix * world): only built if needed)
+    counts = chunk_counts(npix, world, chunk_pixels)
     assert local.shape[0] == counts[rank]
     if len(set(counts)) == 1 and npix % (world * chunk_pixels) == 0:
         flat = torch.empty((npix, 3), dtype=local.dtype, device=local.device)
@@ -215,16 +270,18 @@ def gather_chunks(local, npix, rank, world, chunk_pixels, dist=None):
         rounds = npix // (world * chunk_pixels)
         # flat is [rank][round][chunk_pixels]; the frame is [round][rank][chunk_pixels]
         return flat.view(world, rounds, chunk_pixels, 3).permute(1, 0, 2, 3).reshape(npix, 3)
-    _, index = chunk_owner_map(npix, world, chunk_pixels)
-    m = max(counts)
+    n_chunks = (npix + chunk_pixels - 1) // chunk_pixels
+    per_rank = [len(range(r, n_chunks, world)) for r in range(world)]  # chunks of each rank (the last may be short)
+    m = max(per_rank) * chunk_pixels
     padded = torch.zeros((m, 3), dtype=local.dtype, device=local.device)
     padded[: local.shape[0]] = local
     parts = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(parts, padded)
-    full = torch.empty((npix, 3), dtype=local.dtype, device=local.device)
+    frame = torch.empty((n_chunks, chunk_pixels, 3), dtype=local.dtype, device=local.device)
     for r in range(world):
-        full[index[r].to(local.device)] = parts[r][: counts[r]]
-    return full
+        if per_rank[r]:
+            frame[r::world] = parts[r][: per_rank[r] * chunk_pixels].view(per_rank[r], chunk_pixels, 3)
+    return frame.view(n_chunks * chunk_pixels, 3)[:npix]
 
 
 def gather_bands(local, npix, rank, world, dist=None):

@@ -8,6 +8,8 @@ import pytest
 
 import ptlib
 
+ROOT = ptlib.ROOT
+
 pytestmark = pytest.mark.gpu
 CLI = os.path.join(ptlib.PKG, "ptrace")
 
@@ -76,3 +78,28 @@ def test_cli_fills_an_empty_scenes_directory(tmp_path):
     a = read_ppm(str(out / os.listdir(out)[0]))[3]
     b = read_ppm(str(out2 / os.listdir(out2)[0]))[3]
     assert (a == b).all()
+
+
+@pytest.mark.parametrize("gather", ["torch", "abi"])
+def test_bench_collective_at_world_size_1(gather):
+    """The collective branch of bench.py on hardware with the one GPU this box has: --force-collective initialises
+    torch.distributed with backend "nccl" (= RCCL) and runs all_gather_into_tensor + the strided un-permute (--gather
+    torch), or the C ABI's own communicator and pt_comm_gather_frame (--gather abi), at world size 1; the frame must be
+    the one the plain run gives (bench.py compares the variants' images with the main run's itself, so here: same
+    bounce count and a collective named in the line)."""
+    import json
+    import subprocess
+    import sys
+
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--spp", "8", "--width", "128",
+            "--height", "96", "--no-variants", "--no-cpu-baseline"]
+    plain = subprocess.run(base, capture_output=True, text=True, timeout=600)
+    assert plain.returncode == 0, plain.stderr[-3000:]
+    coll = subprocess.run(base + ["--force-collective", "--gather", gather], capture_output=True, text=True, timeout=600)
+    assert coll.returncode == 0, coll.stderr[-3000:]
+    a = json.loads(plain.stdout.strip().splitlines()[-1])
+    b = json.loads(coll.stdout.strip().splitlines()[-1])
+    assert a["config"]["collective"] is None and b["config"]["collective"]
+    assert ("pt_comm_gather_frame" in b["config"]["collective"]) == (gather == "abi")
+    assert a["config"]["ray_bounces_per_frame"] == b["config"]["ray_bounces_per_frame"] > 0
+    assert b["config"]["image_hash"] == a["config"]["image_hash"]

@@ -91,3 +91,30 @@ def test_chunk_counts_equal_the_owner_map():
         counts, index = pkg.chunk_owner_map(npix, world, chunk)
         assert pkg.chunk_counts(npix, world, chunk) == counts
         assert sum(counts) == npix and all(int(i.numel()) == c for i, c in zip(index, counts))
+
+
+def test_bench_launches_its_own_ranks_and_relays_their_failure():
+    """`python bench.py --gpus 2` outside a launcher starts the two ranks itself (torch.distributed.run as a child, the
+    parent never touching a GPU) and relays their return code.  Here the ranks cannot run - no GPU at all in the build
+    container, a single one on the GPU box - and each says so itself: the failure is the children's message, not a
+    usage error of the parent."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ptlib.ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--spp", "1", "--width", "32", "--height", "24", "--no-variants", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    n_dev = torch.cuda.device_count()
+    if n_dev >= 2:
+        assert r.returncode == 0, r.stderr[-3000:]
+        return
+    assert r.returncode != 0
+    text = r.stdout + r.stderr
+    if n_dev == 0:
+        assert "bench.py needs a GPU" in text and "rank " in text, text[-3000:]
+    else:
+        assert "--gpus 2 needs 2 devices" in text, text[-3000:]
+    assert "usage:" not in text
