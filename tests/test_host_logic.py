@@ -66,3 +66,25 @@ def test_stream_deal_and_partition(tmp_path):
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", inc, "-I", os.path.join(ptlib.ROOT, "include"), str(src),
                            "-o", exe])
     assert subprocess.check_output([exe]).decode().strip() == "OK"
+
+
+def test_rust_shim_mirrors_the_header():
+    """ffi/hip.rs cannot be compiled here (no rustc): hold its #[repr(C)] structs to include/ptrace.h field by field
+    (names and order; emission is the header's spelling of the reference's `emmission`)."""
+    import re
+
+    root = ptlib.ROOT
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "ptrace.h")).read(), flags=re.S)
+    rust = re.sub(r"//[^\n]*", "", open(os.path.join(root, "ffi", "hip.rs")).read())
+    for c_name, r_name in (("pt_camera", "PtCamera"), ("pt_triangle", "PtTriangle"), ("pt_object", "PtObject"),
+                           ("pt_config", "PtConfig"), ("pt_stats", "PtStats")):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (c_name, c_name), header, flags=re.S).group(1)
+        c_fields = re.findall(r"\b(?:float|double|uint32_t|uint64_t)\s+(\w+)", body)
+        rbody = re.search(r"pub struct %s \{(.*?)\n\}" % r_name, rust, flags=re.S).group(1)
+        r_fields = re.findall(r"pub (\w+):", rbody)
+        assert c_fields == r_fields, (c_name, c_fields, r_fields)
+    for name in ("PT_OK", "PT_CANCELLED"):
+        c_val = int(re.search(r"#define %s \(?(-?\d+)\)?" % name, header).group(1))
+        r_val = int(re.search(r"pub const %s: i32 = (-?\d+);" % name, rust).group(1))
+        assert c_val == r_val
+    assert len(re.findall(r"pub fn pt_render\(", rust)) == 1 and "pub fn flatten(" in rust
