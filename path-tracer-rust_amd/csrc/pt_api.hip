@@ -63,6 +63,7 @@ struct Tuning {
     bool pass_kernel = true;   // PT_PASS_KERNEL=0: generate / intersect / shade as separate kernels
     bool pass_bvh = true;      // PT_PASS_BVH=0: BVH scenes through the separate kernels
     bool bvh_lds = false;      // PT_BVH_LDS=1: stage BVH nodes in LDS (separate kernels only)
+    bool cand_scan = true;     // PT_CAND_SCAN=0: k_pass scans every triangle per ray (the round-1 form) instead of candidates
     uint32_t leaf_quorum = 12; // PT_LEAF_QUORUM: lanes on a leaf that send a walking wave to the triangle code
     uint64_t streams = 0;      // PT_STREAMS: ray streams per pass (0 = derived from the frame)
     uint32_t debug = 0;
@@ -76,6 +77,7 @@ static Tuning read_tuning() {
     t.pass_kernel = num("PT_PASS_KERNEL", 1) != 0;
     t.pass_bvh = num("PT_PASS_BVH", 1) != 0;
     t.bvh_lds = num("PT_BVH_LDS", 0) != 0;
+    t.cand_scan = num("PT_CAND_SCAN", 1) != 0;
     t.leaf_quorum = (uint32_t)num("PT_LEAF_QUORUM", 12);
     const long long st = num("PT_STREAMS", 0);
     t.streams = st > 0 ? (uint64_t)st : 0;
@@ -99,6 +101,11 @@ struct pt_ctx {
     DevBuf<MatRec> d_mats;
     DevBuf<TriShade> d_tshade;
     DevBuf<BvhNode> d_nodes;
+    DevBuf<SphPairRec> d_sph;
+    DevBuf<FlatPairRec> d_flat;
+    DevBuf<CandPairRec> d_cand;
+    DevBuf<uint32_t> d_rank_id;
+    bool cand_ok = false;
     uint32_t n_bvh_nodes = 0;
     // Mesh.bounding_box of every object (12 object-local triangles each; Mesh::new's unless pt_ctx_set_mesh_bounds gave
     // the stored ones) and their device form (6 pair records per object), for intersect_bounds / orbit-point queries
@@ -588,6 +595,10 @@ void pt_ctx_destroy(pt_ctx *c) {
     c->d_mats.release();
     c->d_tshade.release();
     c->d_nodes.release();
+    c->d_sph.release();
+    c->d_flat.release();
+    c->d_cand.release();
+    c->d_rank_id.release();
     c->d_boxes.release();
     c->q_o.release();
     c->q_d.release();
@@ -627,7 +638,9 @@ int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uin
     int rc;
     if ((rc = c->d_objs.ensure(fs.objs.size())) || (rc = c->d_opairs.ensure(fs.obj_pairs.size())) || (rc = c->d_tris.ensure(fs.tri_pairs.size())) ||
         (rc = c->d_mats.ensure(fs.mats.size())) || (rc = c->d_tshade.ensure(fs.tri_shade.size())) ||
-        (rc = c->d_nodes.ensure(fs.bvh_nodes.size())))
+        (rc = c->d_nodes.ensure(fs.bvh_nodes.size())) || (rc = c->d_sph.ensure(fs.sph_pairs.size())) ||
+        (rc = c->d_flat.ensure(fs.flat_pairs.size())) || (rc = c->d_cand.ensure(fs.cand_pairs.size())) ||
+        (rc = c->d_rank_id.ensure(fs.rank_id.size())))
         return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (!fs.objs.empty())
@@ -646,6 +659,24 @@ int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uin
     if (!fs.bvh_nodes.empty())
         HIP_TRY(hipMemcpy(c->d_nodes.p, fs.bvh_nodes.data(), fs.bvh_nodes.size() * sizeof(BvhNode),
                           hipMemcpyHostToDevice));
+    if (!fs.sph_pairs.empty())
+        HIP_TRY(hipMemcpy(c->d_sph.p, fs.sph_pairs.data(), fs.sph_pairs.size() * sizeof(SphPairRec), hipMemcpyHostToDevice));
+    if (!fs.flat_pairs.empty())
+        HIP_TRY(hipMemcpy(c->d_flat.p, fs.flat_pairs.data(), fs.flat_pairs.size() * sizeof(FlatPairRec), hipMemcpyHostToDevice));
+    if (!fs.cand_pairs.empty())
+        HIP_TRY(hipMemcpy(c->d_cand.p, fs.cand_pairs.data(), fs.cand_pairs.size() * sizeof(CandPairRec), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_rank_id.p, fs.rank_id.data(), fs.rank_id.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->scene.sph_pairs = c->d_sph.p;
+    c->scene.flat_pairs = c->d_flat.p;
+    c->scene.cand_pairs = c->d_cand.p;
+    c->scene.rank_id = c->d_rank_id.p;
+    c->scene.n_sph_pairs = (uint32_t)fs.sph_pairs.size();
+    c->scene.n_flat_pairs = (uint32_t)fs.flat_pairs.size();
+    c->scene.n_cand_pairs = (uint32_t)fs.cand_pairs.size();
+    c->scene.n_other_pairs = fs.n_other_pairs;
+    c->cand_ok = fs.cand_ok;
+    c->scene.cand_staged = 0u;
+    c->scene.cand_scan = (c->tune.cand_scan && c->cand_ok) ? 1u : 0u;
     c->n_bvh_nodes = (uint32_t)fs.bvh_nodes.size();
     c->scene.bvh_nodes = c->d_nodes.p;
     c->scene.n_bvh_nodes = c->n_bvh_nodes;
@@ -744,6 +775,7 @@ static int render_pipelined(pt_ctx *c, const pt_config *cfg, uint32_t n, uint32_
         p->scene = c->scene;  // device pointers of the parent's scene tables (read-only)
         p->cam = c->cam;
         p->n_bvh_nodes = c->n_bvh_nodes;
+        p->cand_ok = c->cand_ok;
         p->has_scene = true;
         p->profiling = c->profiling;
         cfgs[j].flags &= ~PT_FLAG_PIPELINES(15);
@@ -835,6 +867,7 @@ int pt_ctx_render(pt_ctx *c, const pt_config *cfg, void *d_out_rgb, void *hip_st
     // PT_FLAG_NO_BVH: scan meshes triangle by triangle as the reference does (same result, for A/B checks)
     c->scene.n_bvh_nodes = (cfg->flags & PT_FLAG_NO_BVH) ? 0u : c->n_bvh_nodes;
     c->scene.planar = (cfg->flags & PT_FLAG_NO_BVH) ? 0u : 1u;
+    c->scene.cand_scan = (c->tune.cand_scan && c->cand_ok && !(cfg->flags & PT_FLAG_NO_BVH)) ? 1u : 0u;
     const double t0 = now_ms();
     if (cfg->backend == PT_BACKEND_WAVEFRONT)
         rc = render_wavefront(c, cfg, F, st, cancel, cb, user, stats);
@@ -858,6 +891,7 @@ int pt_ctx_render(pt_ctx *c, const pt_config *cfg, void *d_out_rgb, void *hip_st
     if (stats) stats->ms_total = now_ms() - t0;
     c->scene.n_bvh_nodes = c->n_bvh_nodes;
     c->scene.planar = 1u;
+    c->scene.cand_scan = (c->tune.cand_scan && c->cand_ok) ? 1u : 0u;
     c->live_npix = 0;
     return rc;
 }

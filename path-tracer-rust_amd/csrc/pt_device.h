@@ -89,6 +89,46 @@ constexpr uint32_t kBvhStack = 24;          // per-lane traversal stack entries 
 constexpr uint32_t kBvhMinTris = 16;        // meshes with fewer triangles are scanned linearly
 constexpr uint32_t kBvhMaxLdsNodes = 512;   // 32 KiB of nodes at most are staged in LDS (+ 24 KiB of stacks < 64 KiB)
 
+// ---- candidate scan (k_pass): see intersect_cand -----------------------------------------------------------------
+// Spheres of the scene only, two per record in the order intersect_scene visits them; `rank` = position of the object in
+// the reference's visiting sequence (see DevScene.rank_id).  An odd count gets a filler half (rr = -inf: never hit).
+struct alignas(16) SphPairRec {
+    float cx[2], cy[2], cz[2], rr[2];
+    uint32_t rank[2];
+    uint32_t pad[2];
+};
+// Conservative filter of two pair records (TriPairRec) whose triangles lie in a plane perpendicular to axis `axis`
+// (a = axis, b = a+1, c = a+2 mod 3): the plane coordinate, and the rectangle that bounds the record's two triangles in
+// the other two coordinates as centre / half extent, the half extent already widened by `pad` - the bound on how far from
+// the exact triangle the f32 Moller-Trumbore arithmetic can still accept a ray that is not grazing (|d_a| >= 1/64), plus
+// this filter's own roundoff (pt_host.cpp).  A filler half has pair = kNoPair and an empty rectangle.
+struct alignas(16) FlatPairRec {
+    float pc[2];          // plane coordinate along a
+    float cb[2], hb[2];   // centre, padded half extent along b
+    float cc[2], hc[2];   // centre, padded half extent along c
+    float tpad[2];        // slack on the distance along the ray
+    uint32_t pair[2];     // TriPairRec index
+    uint32_t axis;        // the same for both halves
+    uint32_t pad0;
+};
+constexpr uint32_t kNoPair = 0xffffffffu;
+constexpr float kGrazing = 1.0f / 64.0f;  // |d_a| below this: the filter does not judge, the exact test does
+constexpr uint32_t kCandQueueCap = 192;   // per-wave candidate ring (u16 entries): 63 left over + 2 x 64 pushed by one filter step
+constexpr uint32_t kCandMaxPairs = 512;   // candidate records are numbered in 9 bits of a queue entry
+// What the exact test of a candidate needs, in one record (a copy of the TriPairRec with ids replaced by visiting ranks,
+// plus the bounding-sphere gate of the mesh the two triangles belong to): 7 rows of 16 bytes, gathered per lane from
+// LDS (staged by the workgroup when the scene's records fit) or from global memory.
+struct alignas(16) CandPairRec {
+    float ax[2], ay[2], az[2];
+    float e1x[2], e1y[2], e1z[2];
+    float e2x[2], e2y[2], e2z[2];
+    uint32_t id[2];               // visiting rank of each triangle (kNoTri for a filler half)
+    float gx, gy, gz, grr;        // gate: bounding_sphere.position + position, radius^2 (mod.rs:267-273)
+    float grr_in;                 // see ObjRec.rr_in
+    uint32_t pad[3];
+};
+static_assert(sizeof(CandPairRec) == 112, "7 rows of 16 bytes");
+
 // per-object material record, gathered per lane in shade
 struct alignas(16) MatRec {
     float cr, cg, cb, max_refl;      // color, max(color)                       (mod.rs:667-668)
@@ -117,6 +157,19 @@ struct DevScene {
     uint32_t bvh_pair_base;  // first TriPairRec that is a BVH leaf (leaf references on a u16 stack are relative to it)
     uint32_t leaf_quorum;    // BVH walk: lanes on a leaf that send the wave to the triangle code (see bvh_closest)
     uint32_t planar;         // 0: every triangle through the general test_pair (PT_FLAG_NO_BVH)
+    // candidate scan (scenes without BVH meshes): spheres, filters of the flat pair records, the other pair records
+    // (always candidates), and the visiting ranks: rank of a sphere / triangle = its position in the sequence in which
+    // intersect_scene + Triangle::intersect visit primitives (objects from the last to the first, triangles in list
+    // order), so that "closest, earliest visited among equals" (mod.rs:598,649) is one integer minimum over
+    // (distance bits << 32 | rank).  rank_id maps a rank back to the hit id of HitRec.
+    const SphPairRec *sph_pairs;
+    const FlatPairRec *flat_pairs;  // FlatPairRec.pair = index into cand_pairs
+    const CandPairRec *cand_pairs;  // the pair records of every mesh without a BVH
+    const uint32_t *rank_id;        // [n_objs + n_tris]
+    uint32_t n_sph_pairs, n_flat_pairs, n_cand_pairs;
+    uint32_t n_other_pairs;         // cand_pairs [0, n_other_pairs) have no filter: candidates for every ray
+    uint32_t cand_scan;             // 1: k_pass uses the candidate scan
+    uint32_t cand_staged;           // 1: the workgroup holds cand_pairs in LDS
 };
 
 // per-frame constants
@@ -239,8 +292,8 @@ __device__ __forceinline__ f32x2 f_rcp2(f32x2 d) {
 // triangles per packed instruction.  Updates the mesh-local closest hit (mt, mid).
 //   ORDERED: records are visited in list order, so strict '<' keeps the first of equal distances (mod.rs:598);
 //   otherwise (BVH order) the tie is broken explicitly towards the smaller triangle index: same result.
-template <bool ORDERED>
-__device__ __forceinline__ void test_pair(const TriPairRec &tr, f32x2 ox2, f32x2 oy2, f32x2 oz2, f32x2 dx2, f32x2 dy2,
+template <bool ORDERED, class Rec = TriPairRec>
+__device__ __forceinline__ void test_pair(const Rec &tr, f32x2 ox2, f32x2 oy2, f32x2 oz2, f32x2 dx2, f32x2 dy2,
                                           f32x2 dz2, float &mt, int32_t &mid) {
     const f32x2 e1x = ld2(tr.e1x), e1y = ld2(tr.e1y), e1z = ld2(tr.e1z);
     const f32x2 e2x = ld2(tr.e2x), e2y = ld2(tr.e2y), e2z = ld2(tr.e2z);
@@ -616,6 +669,219 @@ __device__ __forceinline__ HitRec intersect_scene_dev(const DevScene &S, vec3 o,
     }
     if (__builtin_amdgcn_ballot_w64(suspect) != 0ull) h = scan_scene<BVH, true, DEFER_WALK>(S, o, d, lds, want_walk);
     return h;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Candidate scan (scenes whose meshes are all scanned pair by pair - no BVH - i.e. k_pass).
+//
+// intersect_scene tests every ray against every triangle; on the bench scene that is 14 Moller-Trumbore tests per ray of
+// which one or two can succeed, and the loop over objects is wave-uniform: 64 unrelated rays always need all of them.
+// Here the exact test runs only on (ray, pair record) CANDIDATES, and in full waves:
+//   1. every lane tests its ray against the spheres (exactly, two per packed instruction) - the best of them is the
+//      ray's first key - and against a cheap conservative FILTER of each pair record (FlatPairRec: distance to the plane,
+//      point in the padded rectangle, not farther than the best sphere; records without a filter are always candidates);
+//   2. candidates go to a per-wave ring in LDS as (ray slot, record); whenever 64 are queued the wave runs one dense
+//      batch: lane e fetches the ray of entry e's owner (ds_bpermute from the owner's registers), gathers the record per
+//      lane and runs the reference's arithmetic (test_pair: identical bits to the scan's) and the mesh's bounding-sphere
+//      gate (mod.rs:267-273: a mesh whose gate fails contributes nothing), then folds the result into the owner's key
+//      with one LDS atomic minimum.  What is left in the ring (< 64 entries) waits for the next 64 rays of the wave:
+//      k_pass finishes a ray one chunk after it started it, so batches run full;
+//   3. key = (distance bits << 32) | visiting rank: the minimum is the closest hit, the earliest visited among equal
+//      distances - intersect_scene's and Triangle::intersect's strict '<' (mod.rs:598,649) - whatever order the
+//      candidates were processed in.
+// Exactness: the filter may only ever reject a (ray, record) whose exact test would fail or lose: its pads come from the
+// forward-error analysis that sizes the BVH boxes (pt_host.cpp), grazing rays are not judged at all, and a hit farther
+// than the best sphere cannot win.
+struct CandLds {
+    unsigned long long *keys;   // [2][64] of this wave: slot = (chunk parity << 6) | lane
+    float4 *ray_a;              // [2][64]: origin xyz, direction x of the slot's ray
+    float2 *ray_b;              // [2][64]: direction yz
+    uint16_t *queue;            // [kCandQueueCap] ring of this wave: slot | record << 7
+    const CandPairRec *staged;  // the workgroup's LDS copy of DevScene.cand_pairs (STAGED), else unused
+};
+constexpr unsigned long long kKeyMiss = 0x7f800000ffffffffull;  // +inf, last rank
+
+// wave-uniform state of the ring
+struct CandRing {
+    uint32_t head, count;
+};
+
+template <int AXIS>
+__device__ __forceinline__ void filter_flat(const FlatPairRec &f, vec3 o, vec3 d, vec3 inv, float bound, bool *c0, bool *c1) {
+    const float oa = AXIS == 0 ? o.x : (AXIS == 1 ? o.y : o.z), ob = AXIS == 0 ? o.y : (AXIS == 1 ? o.z : o.x),
+                oc = AXIS == 0 ? o.z : (AXIS == 1 ? o.x : o.y);
+    const float da = AXIS == 0 ? d.x : (AXIS == 1 ? d.y : d.z), db = AXIS == 0 ? d.y : (AXIS == 1 ? d.z : d.x),
+                dc = AXIS == 0 ? d.z : (AXIS == 1 ? d.x : d.y);
+    const float ia = AXIS == 0 ? inv.x : (AXIS == 1 ? inv.y : inv.z);
+    const f32x2 t2 = (ld2(f.pc) - splat2(oa)) * splat2(ia);  // distance to the plane (approximate reciprocal)
+    const f32x2 yb = __builtin_elementwise_fma(splat2(db), t2, splat2(ob)) - ld2(f.cb);
+    const f32x2 zc = __builtin_elementwise_fma(splat2(dc), t2, splat2(oc)) - ld2(f.cc);
+    const bool graze = !(f_abs(da) >= kGrazing);  // also when da is NaN
+    const f32x2 lim = splat2(bound) + ld2(f.tpad);
+    bool in[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+        in[hf] = (int)(f_abs(yb[hf]) <= f.hb[hf]) & (int)(f_abs(zc[hf]) <= f.hc[hf]) & (int)(t2[hf] >= -f.tpad[hf]) & (int)(t2[hf] <= lim[hf]);
+    *c0 = (graze | in[0]) & (f.pair[0] != kNoPair);
+    *c1 = (graze | in[1]) & (f.pair[1] != kNoPair);
+}
+
+// intersect_sphere against the scene's spheres (mod.rs:412-427), two per record, in visiting order (strict '<' keeps
+// the first): the ray's first key
+__device__ __forceinline__ unsigned long long cand_spheres(const DevScene &S, vec3 o, vec3 d, float *best_out) {
+    float best_t = __builtin_inff();
+    uint32_t best_rank = 0xffffffffu;
+    const f32x2 ox2 = splat2(o.x), oy2 = splat2(o.y), oz2 = splat2(o.z);
+    const f32x2 dx2 = splat2(d.x), dy2 = splat2(d.y), dz2 = splat2(d.z);
+    for (uint32_t p = 0; p < S.n_sph_pairs; ++p) {
+        const SphPairRec sp = ld_uniform(S.sph_pairs + p);
+        const f32x2 opx = ld2(sp.cx) - ox2, opy = ld2(sp.cy) - oy2, opz = ld2(sp.cz) - oz2;
+        const f32x2 b = (opx * dx2 + opy * dy2) + opz * dz2;
+        const f32x2 det = (b * b - ((opx * opx + opy * opy) + opz * opz)) + ld2(sp.rr);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            if (__builtin_amdgcn_ballot_w64(!(det[hf] < 0.0f)) == 0ull) continue;  // no lane of the wave hits this one
+            const float sq = f_sqrt(det[hf]);  // NaN when det < 0: both comparisons below are then false
+            const float t0 = b[hf] - sq, t1 = b[hf] + sq;
+            const bool near_ok = t0 >= 1e-4f, far_ok = t1 >= 1e-4f;
+            const float t = near_ok ? t0 : t1;
+            if (!(det[hf] < 0.0f) && (near_ok || far_ok) && t < best_t) {
+                best_t = t;
+                best_rank = sp.rank[hf];
+            }
+        }
+    }
+    *best_out = best_t;
+    return ((unsigned long long)__float_as_uint(best_t) << 32) | best_rank;
+}
+
+// One dense batch: the `count` (<= 64) oldest ring entries.  Every lane of the wave takes part.  An entry's ray is read
+// from its slot in LDS (k_pass_cand keeps the rays of the two chunks in flight there).
+template <bool STAGED>
+__device__ __forceinline__ void cand_batch(const DevScene &S, const CandLds &L, CandRing &R, uint32_t lane, uint32_t count) {
+    const bool valid = lane < count;
+    uint32_t at = R.head + lane;
+    at = at >= kCandQueueCap ? at - kCandQueueCap : at;
+    R.head += count;
+    R.head = R.head >= kCandQueueCap ? R.head - kCandQueueCap : R.head;
+    R.count -= count;
+    if (valid) {
+        const uint32_t ent = (uint32_t)L.queue[at];
+        const uint32_t slot = ent & 127u, q = ent >> 7;
+        const float4 ra = L.ray_a[slot];
+        const float2 rb = L.ray_b[slot];
+        const vec3 ro = mk(ra.x, ra.y, ra.z), rd = mk(ra.w, rb.x, rb.y);
+        CandPairRec tr;
+        if (STAGED)
+            tr = L.staged[q];  // per-lane gather from LDS
+        else
+            tr = S.cand_pairs[q];
+        // Triangle::intersect's arithmetic for both triangles of the record (mod.rs:559-589), as in test_pair
+        const f32x2 ox2 = splat2(ro.x), oy2 = splat2(ro.y), oz2 = splat2(ro.z);
+        const f32x2 dx2 = splat2(rd.x), dy2 = splat2(rd.y), dz2 = splat2(rd.z);
+        const f32x2 e1x = ld2(tr.e1x), e1y = ld2(tr.e1y), e1z = ld2(tr.e1z);
+        const f32x2 e2x = ld2(tr.e2x), e2y = ld2(tr.e2y), e2z = ld2(tr.e2z);
+        const f32x2 px = dy2 * e2z - e2y * dz2, py = dz2 * e2x - e2z * dx2, pz = dx2 * e2y - e2x * dy2;
+        const f32x2 determinant = (e1x * px + e1y * py) + e1z * pz;
+        const f32x2 inv_det = f_rcp2(determinant);
+        const f32x2 tx = ox2 - ld2(tr.ax), ty = oy2 - ld2(tr.ay), tz = oz2 - ld2(tr.az);
+        const f32x2 u = ((tx * px + ty * py) + tz * pz) * inv_det;
+        const f32x2 qx = ty * e1z - e1y * tz, qy = tz * e1x - e1z * tx, qz = tx * e1y - e1x * ty;
+        const f32x2 v = ((dx2 * qx + dy2 * qy) + dz2 * qz) * inv_det;
+        const f32x2 dist = ((e2x * qx + e2y * qy) + e2z * qz) * inv_det;
+        // The five rejections of mod.rs:571-592 as ONE sign bit per triangle, built with two-cycle integer instructions
+        // instead of compares and selects (4 cycles each, profiles/r02_valu_issue_costs.json):
+        //   u < 0, v < 0, u + v > 1   <=> the sign bit of (u + 0) | (v + 0) | (1 - (u + v)): adding +0 turns a -0 into
+        //                                 +0 (the reference keeps u = -0: `u < 0.0` is false), 1 - s is negative exactly
+        //                                 when s > 1 (s, 1 are floats: the difference has the sign of the real one), and
+        //                                 u > 1 is implied by u + v > 1 (test_pair).  NaN cannot occur with |det| >= 1e-4;
+        //   |det| < 1e-4              <=> (bits(det) & 0x7fffffff) - bits(1e-4) is negative as an integer.
+        // A rejected triangle gets the sign bit OR-ed into the bits of its distance; k = bits - 1 then maps
+        //   distance > 0 (accepted)  ->  bits - 1 in [0, 0x7f7fffff]: order and ties of the distances are kept,
+        //   +0                       ->  0xffffffff,   negative / -0 / rejected  ->  >= 0x7fffffff,
+        // all three above every accepted value and above the "no hit" key 0x7f800000 - 1, so they never win.
+        const f32x2 zero = splat2(0.0f);
+        const f32x2 s_uv = (u + zero) + (v + zero);
+        const f32x2 w = splat2(1.0f) - s_uv;
+        unsigned long long keys2[2];
+        float t_hit[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const uint32_t ub = __float_as_uint(u[hf] + 0.0f), vb = __float_as_uint(v[hf] + 0.0f), wb = __float_as_uint(w[hf]);
+            const uint32_t db = (__float_as_uint(determinant[hf]) & 0x7fffffffu) - 0x38d1b717u;  // bits(1e-4f)
+            const uint32_t bad = (ub | vb | wb | db) & 0x80000000u;
+            const uint32_t k = (__float_as_uint(dist[hf]) | bad) - 1u;
+            keys2[hf] = ((unsigned long long)k << 32) | tr.id[hf];
+            t_hit[hf] = dist[hf];
+        }
+        // the mesh's gate (mod.rs:267-273), for the nearer accepted triangle of the record (a gate that fails rejects
+        // both: it depends on the ray and the mesh only).  Usually the hit point lies well inside the bounding sphere
+        // (ObjRec.rr_in: then the f32 gate cannot fail); otherwise intersect_sphere(...).is_some() as the reference does.
+        const bool first = keys2[0] <= keys2[1];
+        const unsigned long long kmin = first ? keys2[0] : keys2[1];
+        const float mt = first ? t_hit[0] : t_hit[1];
+        bool pass = (uint32_t)(kmin >> 32) < 0x7f800000u;
+        const vec3 g = mk(tr.gx, tr.gy, tr.gz);
+        const vec3 pc = (ro + rd * mt) - g;
+        const bool deep = dot(pc, pc) <= tr.grr_in;  // false on NaN / when no shortcut is offered
+        if (pass && !deep) {
+            const vec3 og = g - ro;
+            const float b = dot(og, rd);
+            const float det = (b * b - dot(og, og)) + tr.grr;
+            const float sq = f_sqrt(det);
+            pass = !(det < 0.0f) && ((b - sq) >= 1e-4f || (b + sq) >= 1e-4f);
+        }
+        // key of a hit = (bits(distance) << 32) | rank; k holds bits - 1: adding 1 << 32 restores it
+        if (pass) atomicMin(&L.keys[slot], kmin + (1ull << 32));
+    }
+}
+
+// Filters of the current chunk's ray (o, d; `valid` lanes) -> ring; full batches are run as they fill up.  `par` is the
+// chunk's parity (its slots).
+template <bool STAGED>
+__device__ __forceinline__ void cand_filter_and_drain(const DevScene &S, const CandLds &L, CandRing &R, uint32_t lane,
+                                                      uint32_t par, bool valid, vec3 o, vec3 d, float bound) {
+    // both halves of a filter record in one step: entries of half 0 first, then half 1
+    auto push2 = [&](bool c0, uint32_t q0, bool c1, uint32_t q1) {
+        const uint64_t m0 = __builtin_amdgcn_ballot_w64(c0), m1 = __builtin_amdgcn_ballot_w64(c1);
+        if ((m0 | m1) == 0ull) return;
+        const uint32_t n0 = (uint32_t)__builtin_popcountll(m0);
+        const uint32_t base = R.head + R.count;
+        const uint32_t me = lane | (par << 6);
+        if (c0) {
+            uint32_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
+            at = at >= kCandQueueCap ? at - kCandQueueCap : at;
+            at = at >= kCandQueueCap ? at - kCandQueueCap : at;
+            L.queue[at] = (uint16_t)(me | (q0 << 7));
+        }
+        if (c1) {
+            uint32_t at = base + n0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+            at = at >= kCandQueueCap ? at - kCandQueueCap : at;
+            at = at >= kCandQueueCap ? at - kCandQueueCap : at;
+            L.queue[at] = (uint16_t)(me | (q1 << 7));
+        }
+        R.count += n0 + (uint32_t)__builtin_popcountll(m1);
+    };
+    auto drain = [&]() {
+        while (R.count >= 64u) cand_batch<STAGED>(S, L, R, lane, 64u);
+    };
+    const vec3 inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    for (uint32_t p = 0; p < S.n_flat_pairs; ++p) {
+        const FlatPairRec f = ld_uniform(S.flat_pairs + p);
+        bool c0, c1;
+        if (f.axis == 0u)
+            filter_flat<0>(f, o, d, inv, bound, &c0, &c1);
+        else if (f.axis == 1u)
+            filter_flat<1>(f, o, d, inv, bound, &c0, &c1);
+        else
+            filter_flat<2>(f, o, d, inv, bound, &c0, &c1);
+        push2(valid & c0, f.pair[0], valid & c1, f.pair[1]);
+        drain();
+    }
+    for (uint32_t q = 0; q < S.n_other_pairs; ++q) {  // records without a filter: a candidate for every ray
+        push2(valid, q, false, 0u);
+        drain();
+    }
 }
 
 // The BVH walks of a ray whose other objects are done (best_t / best_id hold their winner): every mesh with a BVH, in

@@ -432,6 +432,136 @@ bool flatten_scene(const pt_camera &cam, const pt_object *objs, uint32_t n_objs,
             pr.admit[hf] = 0u;
         }
     }
+    // ---- tables of the candidate scan (intersect_cand) -----------------------------------------------------------
+    // ranks: the reference's visiting sequence - objects from the last to the first (mod.rs:637), a mesh's triangles in
+    // list order (mod.rs:558)
+    std::vector<uint32_t> tri_rank(n_tris ? n_tris : 1u, 0u);
+    out.rank_id.assign((size_t)n_objs + n_tris + 1u, 0u);
+    std::vector<uint32_t> obj_rank(n_objs, 0u);
+    {
+        uint32_t next = 0;
+        for (uint32_t v = 0; v < n_objs; ++v) {
+            const uint32_t i = n_objs - 1u - v;
+            obj_rank[i] = next;
+            if (objs[i].kind == PT_SPHERE) {
+                out.rank_id[next++] = i;
+            } else {
+                for (uint32_t k = 0; k < objs[i].tri_count; ++k) {
+                    tri_rank[objs[i].tri_offset + k] = next;
+                    out.rank_id[next++] = n_objs + objs[i].tri_offset + k;
+                }
+            }
+        }
+    }
+    out.sph_pairs.clear();
+    out.flat_pairs.clear();
+    out.cand_pairs.clear();
+    std::vector<CandPairRec> filtered;  // records that have a filter (appended after the unfiltered ones below)
+    // the exact-test record of pair record pp of object i
+    auto cand_rec = [&](uint32_t i, uint32_t pp) {
+        const TriPairRec &tp = out.tri_pairs[pp];
+        CandPairRec c{};
+        for (int hf = 0; hf < 2; ++hf) {
+            c.ax[hf] = tp.ax[hf], c.ay[hf] = tp.ay[hf], c.az[hf] = tp.az[hf];
+            c.e1x[hf] = tp.e1x[hf], c.e1y[hf] = tp.e1y[hf], c.e1z[hf] = tp.e1z[hf];
+            c.e2x[hf] = tp.e2x[hf], c.e2y[hf] = tp.e2y[hf], c.e2z[hf] = tp.e2z[hf];
+            c.id[hf] = tp.id[hf] == kNoTri ? kNoTri : tri_rank[tp.id[hf]];
+        }
+        c.gx = out.objs[i].cx, c.gy = out.objs[i].cy, c.gz = out.objs[i].cz;
+        c.grr = out.objs[i].rr;
+        c.grr_in = out.objs[i].rr_in;
+        return c;
+    };
+    {
+        const float ninf = -std::numeric_limits<float>::infinity();
+        uint32_t n_sph = 0;
+        for (uint32_t v = 0; v < n_objs; ++v) {
+            const uint32_t i = n_objs - 1u - v;
+            if (objs[i].kind != PT_SPHERE) continue;
+            if ((n_sph & 1u) == 0u) {
+                SphPairRec f{};
+                f.rr[0] = f.rr[1] = ninf;
+                out.sph_pairs.push_back(f);
+            }
+            SphPairRec &sp = out.sph_pairs.back();
+            const uint32_t hf = n_sph & 1u;
+            sp.cx[hf] = out.objs[i].cx, sp.cy[hf] = out.objs[i].cy, sp.cz[hf] = out.objs[i].cz, sp.rr[hf] = out.objs[i].rr;
+            sp.rank[hf] = obj_rank[i];
+            ++n_sph;
+        }
+        // pair records of meshes without a BVH: flat ones (both triangles in one axis-aligned plane) get a filter,
+        // grouped by axis so that two of them share a record; the rest are candidates for every ray
+        std::vector<FlatPairRec> by_axis[3];
+        uint32_t fill[3] = {0, 0, 0};
+        for (uint32_t i = 0; i < n_objs; ++i) {
+            const ObjRec &r = out.objs[i];
+            if (r.kind != kKindMesh || r.bvh_root != kNoBvh) continue;
+            for (uint32_t pp = r.pair_begin; pp < r.pair_begin + r.pair_count; ++pp) {
+                const TriPairRec &tp = out.tri_pairs[pp];
+                int axis = -1;
+                for (int ax = 0; ax < 3 && axis < 0; ++ax) {
+                    const float *e1 = ax == 0 ? tp.e1x : (ax == 1 ? tp.e1y : tp.e1z);
+                    const float *e2 = ax == 0 ? tp.e2x : (ax == 1 ? tp.e2y : tp.e2z);
+                    const float *aa = ax == 0 ? tp.ax : (ax == 1 ? tp.ay : tp.az);
+                    const bool two = tp.id[1] != kNoTri;
+                    if (e1[0] == 0.0f && e2[0] == 0.0f && (!two || (e1[1] == 0.0f && e2[1] == 0.0f && aa[1] == aa[0]))) axis = ax;
+                }
+                // |N| of the record's triangles (the smaller one), their longest edge, their bounds in the plane
+                float n_min = std::numeric_limits<float>::infinity(), L = 0.0f;
+                vec3 lo = mk(finf, finf, finf), hi = mk(-finf, -finf, -finf);
+                for (int hf = 0; hf < 2; ++hf) {
+                    if (tp.id[hf] == kNoTri) continue;
+                    const vec3 a = mk(tp.ax[hf], tp.ay[hf], tp.az[hf]);
+                    const vec3 e1 = mk(tp.e1x[hf], tp.e1y[hf], tp.e1z[hf]), e2 = mk(tp.e2x[hf], tp.e2y[hf], tp.e2z[hf]);
+                    n_min = std::fmin(n_min, length(cross(e1, e2)));
+                    L = std::fmax(L, std::fmax(length(e1), std::fmax(length(e2), length(e2 - e1))));
+                    BvhBuilder::grow(lo, hi, a, a);
+                    BvhBuilder::grow(lo, hi, a + e1, a + e1);
+                    BvhBuilder::grow(lo, hi, a + e2, a + e2);
+                }
+                // The filter only judges rays with |d_a| >= kGrazing, for which |determinant| = |d_a| |N| >= |N| / 64
+                // (and >= 1e-4, mod.rs:571): the forward-error bound of the BVH boxes above with that determinant in
+                // place of 1e-4, plus the filter's own arithmetic (an approximate reciprocal and two fmas on
+                // distances up to 64 R).
+                const float e = 5.9604645e-8f;
+                const float det_min = std::fmax(1e-4f, n_min * kGrazing);
+                const float pad = 3.0f * (16.0f * e * L * L * (scene_R + L) / det_min) + 2048.0f * e * (scene_R + L) + 1e-5f;
+                const bool usable = axis >= 0 && std::isfinite(pad) && std::isfinite(n_min) && n_min > 0.0f;
+                if (!usable) {
+                    out.cand_pairs.push_back(cand_rec(i, pp));
+                    continue;
+                }
+                const int a = axis, b = (axis + 1) % 3, c = (axis + 2) % 3;
+                const float lov[3] = {lo.x, lo.y, lo.z}, hiv[3] = {hi.x, hi.y, hi.z};
+                if ((fill[a] & 1u) == 0u) {
+                    FlatPairRec f{};
+                    f.pair[0] = f.pair[1] = kNoPair;
+                    f.hb[0] = f.hb[1] = f.hc[0] = f.hc[1] = -1.0f;  // empty rectangle: |x - c| <= -1 never holds
+                    f.tpad[0] = f.tpad[1] = 0.0f;
+                    f.axis = (uint32_t)a;
+                    by_axis[a].push_back(f);
+                }
+                FlatPairRec &f = by_axis[a].back();
+                const uint32_t hf = fill[a] & 1u;
+                f.pc[hf] = lov[a];
+                f.cb[hf] = 0.5f * (lov[b] + hiv[b]);
+                f.hb[hf] = 0.5f * (hiv[b] - lov[b]) + pad + 4.0f * e * (f_abs(lov[b]) + f_abs(hiv[b]));
+                f.cc[hf] = 0.5f * (lov[c] + hiv[c]);
+                f.hc[hf] = 0.5f * (hiv[c] - lov[c]) + pad + 4.0f * e * (f_abs(lov[c]) + f_abs(hiv[c]));
+                f.tpad[hf] = pad;
+                f.pair[hf] = (uint32_t)filtered.size();  // + n_other_pairs below
+                filtered.push_back(cand_rec(i, pp));
+                ++fill[a];
+            }
+        }
+        for (int a = 0; a < 3; ++a) out.flat_pairs.insert(out.flat_pairs.end(), by_axis[a].begin(), by_axis[a].end());
+        out.n_other_pairs = (uint32_t)out.cand_pairs.size();
+        for (FlatPairRec &f : out.flat_pairs)
+            for (int hf = 0; hf < 2; ++hf)
+                if (f.pair[hf] != kNoPair) f.pair[hf] += out.n_other_pairs;
+        out.cand_pairs.insert(out.cand_pairs.end(), filtered.begin(), filtered.end());
+        out.cand_ok = !have_bvh && out.cand_pairs.size() <= kCandMaxPairs;
+    }
     return true;
 }
 

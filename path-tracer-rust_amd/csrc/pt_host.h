@@ -20,6 +20,12 @@ struct FlatScene {
     std::vector<MatRec> mats;
     std::vector<TriShade> tri_shade;
     std::vector<BvhNode> bvh_nodes;
+    std::vector<SphPairRec> sph_pairs;
+    std::vector<FlatPairRec> flat_pairs;
+    std::vector<CandPairRec> cand_pairs;  // [0, n_other_pairs): records without a filter
+    std::vector<uint32_t> rank_id;
+    uint32_t n_other_pairs = 0;
+    bool cand_ok = false;  // the scene can use the candidate scan (no BVH mesh, records numbered in 9 bits)
     uint32_t bvh_pair_base = 0;  // first TriPairRec that is a BVH leaf
     uint32_t bvh_pair_span = 0;  // leaves lie in [bvh_pair_base, bvh_pair_base + bvh_pair_span)
 };

@@ -41,6 +41,18 @@ __host__ __device__ constexpr size_t pass_lds_defer_offset(uint32_t m) {
     return ((size_t)3 * m * sizeof(unsigned long long) + 16 + (size_t)m * sizeof(uint32_t) + 15) & ~(size_t)15;
 }
 
+// k_pass_cand LDS: [accumulators, tails, pixel indices as k_pass][per wave: float4 ray_a [128] | u64 key [128] |
+// float2 ray_b [128] | u16 ring [kCandQueueCap]][staged candidate records]
+// (with glass deferral: kCandDeferCap entries per wave before them; a wave shades its deferred glass hits as soon as
+// kCandDeferFlush are waiting, so 31 left over + 64 new fit)
+constexpr uint32_t kCandDeferCap = 96, kCandDeferFlush = 32;
+__host__ __device__ constexpr size_t pass_lds_cand_offset(uint32_t m, bool defer) {
+    return pass_lds_defer_offset(m) + (defer ? (size_t)(kBlock / 64u) * 3u * kCandDeferCap * sizeof(float4) : 0u);
+}
+constexpr size_t kCandWaveBytes = 128u * 16u + 128u * 8u + 128u * 8u + kCandQueueCap * 2u;  // 4480
+__host__ __device__ constexpr size_t pass_lds_cand_bytes() { return (size_t)(kBlock / 64u) * kCandWaveBytes; }
+static_assert(kCandWaveBytes % 16u == 0u, "per-wave areas stay 16-byte aligned");
+
 __device__ __forceinline__ uint32_t lane_prefix(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
@@ -455,6 +467,235 @@ __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, R
     __syncthreads();
     if (tid == 0) blk_rays[b] += total;
     // flush once per pass: this workgroup is the only writer of its pixels, launches on the stream are ordered
+    const size_t plane = (size_t)F.n_streams * m;
+    for (uint32_t k = tid; k < 3u * mb; k += kBlock) {
+        const uint32_t c = k / mb, p = k - c * mb;
+        const unsigned long long v = lds_acc[c * m + p];
+        if (v) acc[(size_t)c * plane + (size_t)b * m + p] += v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_pass with the candidate scan (pt_device.h: "Candidate scan"): the same walk of a stream, but a ray is FINISHED one
+// chunk after it was started.  Trip `it` of the chunk loop loads (or generates) the rays of chunk `it`, puts origin and
+// direction into the chunk's slots in LDS, tests the spheres, runs the filters and queues the candidates; full batches of
+// 64 candidates are run as the ring fills; then every candidate of chunk `it - 1` has been through a batch (they were
+// the oldest entries of the ring), so the rays of chunk `it - 1` take their hit from their key, are shaded and appended.
+// One trip beyond the last chunk flushes the ring.  Streams, levels, accumulators and the final flush are k_pass's;
+// glass hits are shaded in place (the deferral buffers' LDS is what the ray slots use here).
+template <bool STAGED, bool DEFER>
+__global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams F, RayQueue q0, RayQueue q1, uint32_t cap,
+                                                         uint32_t s0, uint32_t s_here, uint32_t m,
+                                                         unsigned long long *__restrict__ acc,
+                                                         unsigned long long *__restrict__ blk_rays,
+                                                         uint32_t *__restrict__ flags) {
+    unsigned long long *lds_acc = reinterpret_cast<unsigned long long *>(dyn_lds);
+    uint32_t *s_tail_p = reinterpret_cast<uint32_t *>(lds_acc + 3u * m);
+    const uint32_t b = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t mb = stream_pixel_count(F.npix, F.n_streams, b);  // <= m
+    if (mb == 0u) return;
+    for (uint32_t k = tid; k < 3u * m; k += kBlock) lds_acc[k] = 0ull;
+    if (tid == 0) s_tail_p[0] = s_tail_p[1] = 0u;
+    uint32_t *lds_pix = s_tail_p + 4;
+    for (uint32_t j = tid; j < mb; j += kBlock) lds_pix[j] = global_pixel(F, stream_pixel(F.n_streams, b, j));
+    CandLds cand;
+    {
+        char *cbase = reinterpret_cast<char *>(dyn_lds) + pass_lds_cand_offset(m, DEFER);
+        char *wbase = cbase + (size_t)(tid >> 6) * kCandWaveBytes;
+        cand.ray_a = reinterpret_cast<float4 *>(wbase);
+        cand.keys = reinterpret_cast<unsigned long long *>(wbase + 128u * 16u);
+        cand.ray_b = reinterpret_cast<float2 *>(wbase + 128u * 24u);
+        cand.queue = reinterpret_cast<uint16_t *>(wbase + 128u * 32u);
+        char *sbase = cbase + pass_lds_cand_bytes();
+        cand.staged = reinterpret_cast<const CandPairRec *>(sbase);
+        if (STAGED) {  // the workgroup's own copy of the candidate records
+            const uint4 *src = reinterpret_cast<const uint4 *>(S.cand_pairs);
+            uint4 *dst = reinterpret_cast<uint4 *>(sbase);
+            for (uint32_t k = tid; k < S.n_cand_pairs * (uint32_t)(sizeof(CandPairRec) / 16u); k += kBlock) dst[k] = src[k];
+        }
+    }
+    const size_t base = (size_t)b * cap;
+    ShadeParams P;
+    P.idx_begin = F.idx_begin;
+    P.npix = F.npix;
+    P.n_streams = F.n_streams;
+    P.seed_lo = F.seed_lo;
+    P.seed_hi = F.seed_hi;
+    P.debug = F.debug;
+    P.s0 = s0;
+    P.chunk_pixels = F.chunk_pixels;
+    P.chunk_first = F.chunk_first;
+    P.chunk_step = F.chunk_step;
+    bool overflow = false;
+    unsigned long long total = 0ull;
+    uint32_t n = mb * s_here;  // rays of the current level
+    StreamSlice qout{};
+    uint32_t *tail_p = nullptr;
+    auto append = [&](const ShadeOut &so, uint32_t word) {
+        const uint64_t m1 = __builtin_amdgcn_ballot_w64(so.n_rays >= 1);
+        const uint64_t m2 = __builtin_amdgcn_ballot_w64(so.n_rays == 2);
+        const uint32_t c1 = (uint32_t)__builtin_popcountll(m1), c2 = (uint32_t)__builtin_popcountll(m2);
+        if ((c1 + c2) == 0u) return;  // wave-uniform
+        uint32_t wbase = 0;
+        if (lane == 0u) wbase = atomicAdd(tail_p, c1 + c2);
+        wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+        if (so.n_rays >= 1) {
+            const uint32_t slot = wbase + lane_prefix(m1);
+            if (slot < cap)
+                store_ray(qout, slot, so.x, so.d0, so.thr0,
+                          pack_word(word_pix(word), word_sample(word), meta_depth(so.meta0), meta_branch(so.meta0)));
+            else
+                overflow = true;
+        }
+        if (so.n_rays == 2) {
+            const uint32_t slot = wbase + c1 + lane_prefix(m2);
+            if (slot < cap)
+                store_ray(qout, slot, so.x, so.d1, so.thr1,
+                          pack_word(word_pix(word), word_sample(word), meta_depth(so.meta1), meta_branch(so.meta1)));
+            else
+                overflow = true;
+        }
+    };
+    // glass hits of this wave wait in LDS until kCandDeferFlush of them make a dense wave (see k_pass)
+    float4 *const dbuf = reinterpret_cast<float4 *>(reinterpret_cast<char *>(dyn_lds) + pass_lds_defer_offset(m)) +
+                         (size_t)(tid >> 6) * (3u * kCandDeferCap);
+    uint32_t n_defer = 0;  // wave-uniform
+    auto shade_deferred = [&](uint32_t e, bool valid) {
+        ShadeOut so;
+        so.n_rays = 0;
+        so.emits = false;
+        uint32_t word = 0;
+        if (valid) {
+            const float4 a = dbuf[e], bq = dbuf[kCandDeferCap + e], cq = dbuf[2u * kCandDeferCap + e];
+            PathRay in;
+            in.o = mk(a.x, a.y, a.z);
+            in.d = mk(a.w, bq.x, bq.y);
+            in.thr = mk(bq.z, bq.w, cq.x);
+            word = __float_as_uint(cq.y);
+            HitRec h;
+            h.t = cq.z;
+            h.id = __float_as_int(cq.w);
+            in.pix = lds_pix[word_pix(word)];
+            in.meta = pack_meta(s0 + word_sample(word), word_depth(word), word_branch(word));
+            shade_hit<kShadeRefractOnly>(S, P, in, h, so);
+            if (so.emits) add_radiance_lds(lds_acc, m, word_pix(word), so.contrib);
+        }
+        append(so, word);
+    };
+    CandRing ring;
+    ring.head = 0u;
+    ring.count = 0u;
+    for (uint32_t depth = 0; depth < (uint32_t)kMaxDepth && n != 0u; ++depth) {
+        const StreamSlice qin = slice_of((depth & 1u) ? q1 : q0, base);  // level 0 is never stored
+        qout = slice_of((depth & 1u) ? q0 : q1, base);
+        __syncthreads();  // level `depth` of the stream is complete and visible (and, the first time, the staged records)
+        if (tid == 0) s_tail_p[(depth + 1u) & 1u] = 0u;
+        tail_p = s_tail_p + (depth & 1u);
+        total += n;
+        const uint32_t n_chunks = (n + kBlock - 1u) / kBlock;
+        vec3 prev_thr = mk(0.0f, 0.0f, 0.0f);  // what the ray started in the trip before still needs from registers
+        uint32_t prev_word = 0;
+        bool prev_valid = false;
+        for (uint32_t it = 0; it <= n_chunks; ++it) {  // uniform trip count; the last trip only finishes chunk n_chunks - 1
+            const uint32_t par = it & 1u;
+            const uint32_t i = it * kBlock + tid;
+            const bool cur_valid = it < n_chunks && i < n;
+            vec3 cur_thr = mk(0.0f, 0.0f, 0.0f);
+            uint32_t word = 0;
+            const uint32_t pending = ring.count;  // entries of chunk it - 1 still queued (< 64)
+            bool ran_batch = false;
+            if (it < n_chunks) {
+                PathRay in;
+                in.o = in.d = in.thr = mk(0.0f, 0.0f, 0.0f);
+                if (cur_valid) {
+                    if (depth == 0u) {  // render_pixel's ray for (pixel i % mb of the stream, sample s0 + i / mb)
+                        const uint32_t pj = i % mb, sj = i / mb;
+                        in = primary_ray(F, lds_pix[pj], s0 + sj);
+                        word = pack_word(pj, sj, 0u, 1u);
+                    } else {
+                        const float4 a = *reinterpret_cast<const float4 *>(qin.od0 + i * 16u);
+                        const float4 tp = *reinterpret_cast<const float4 *>(qin.tp + i * 16u);
+                        const float2 c = *reinterpret_cast<const float2 *>(qin.od1 + i * 8u);
+                        in.o = mk(a.x, a.y, a.z);
+                        in.d = mk(a.w, c.x, c.y);
+                        in.thr = mk(tp.x, tp.y, tp.z);
+                        word = __float_as_uint(tp.w);
+                    }
+                }
+                cur_thr = in.thr;
+                const uint32_t slot = (par << 6) | lane;
+                cand.ray_a[slot] = make_float4(in.o.x, in.o.y, in.o.z, in.d.x);
+                cand.ray_b[slot] = make_float2(in.d.y, in.d.z);
+                float bound;
+                const unsigned long long key0 = cand_spheres(S, in.o, in.d, &bound);
+                cand.keys[slot] = cur_valid ? key0 : kKeyMiss;
+                const uint32_t before = ring.head;
+                cand_filter_and_drain<STAGED>(S, cand, ring, lane, par, cur_valid, in.o, in.d, bound);
+                ran_batch = ring.head != before;
+            }
+            if (it > 0u) {
+                // chunk it - 1: its candidates were the oldest entries of the ring; if no full batch ran in this trip (few
+                // candidates, or the flushing trip) run what is queued now
+                if (pending != 0u && !ran_batch) cand_batch<STAGED>(S, cand, ring, lane, ring.count);
+                ShadeOut so;
+                so.n_rays = 0;
+                so.emits = false;
+                so.deferred = false;
+                HitRec h;
+                h.t = 0.0f;
+                h.id = -1;
+                PathRay pr;
+                pr.o = pr.d = pr.thr = mk(0.0f, 0.0f, 0.0f);
+                if (prev_valid) {
+                    const uint32_t slot = ((par ^ 1u) << 6) | lane;
+                    const unsigned long long key = cand.keys[slot];
+                    const uint32_t rank = (uint32_t)key;
+                    if (rank != 0xffffffffu) {
+                        h.t = __uint_as_float((uint32_t)(key >> 32));
+                        h.id = (int32_t)S.rank_id[rank];
+                        const float4 ra = cand.ray_a[slot];
+                        const float2 rb = cand.ray_b[slot];
+                        pr.o = mk(ra.x, ra.y, ra.z);
+                        pr.d = mk(ra.w, rb.x, rb.y);
+                        pr.thr = prev_thr;
+                        pr.pix = lds_pix[word_pix(prev_word)];
+                        pr.meta = pack_meta(s0 + word_sample(prev_word), word_depth(prev_word), word_branch(prev_word));
+                        shade_hit<DEFER ? kShadeDeferRefract : kShadeAll>(S, P, pr, h, so);
+                        if (so.emits) add_radiance_lds(lds_acc, m, word_pix(prev_word), so.contrib);
+                    }
+                }
+                append(so, prev_word);
+                const uint64_t md = DEFER ? __builtin_amdgcn_ballot_w64(so.deferred) : 0ull;
+                if (DEFER && md != 0ull) {
+                    if (so.deferred) {
+                        const uint32_t e = n_defer + lane_prefix(md);
+                        dbuf[e] = make_float4(pr.o.x, pr.o.y, pr.o.z, pr.d.x);
+                        dbuf[kCandDeferCap + e] = make_float4(pr.d.y, pr.d.z, pr.thr.x, pr.thr.y);
+                        dbuf[2u * kCandDeferCap + e] = make_float4(pr.thr.z, __uint_as_float(prev_word), h.t, __int_as_float(h.id));
+                    }
+                    n_defer += (uint32_t)__builtin_popcountll(md);
+                }
+                if (DEFER && n_defer >= kCandDeferFlush) {  // wave-uniform
+                    const uint32_t cnt = n_defer < 64u ? n_defer : 64u;
+                    n_defer -= cnt;
+                    shade_deferred(n_defer + lane, lane < cnt);
+                }
+            }
+            prev_thr = cur_thr;
+            prev_word = word;
+            prev_valid = cur_valid;
+        }
+        if (DEFER && n_defer != 0u) {  // the rest of this wave's glass hits of the level (k_pass: carrying them over loses)
+            shade_deferred(lane, lane < n_defer);
+            n_defer = 0u;
+        }
+        __syncthreads();  // every append of this level is counted
+        const uint32_t tail = *tail_p;
+        n = tail < cap ? tail : cap;
+    }
+    if (overflow) atomicOr(flags, 1u);
+    __syncthreads();
+    if (tid == 0) blk_rays[b] += total;
     const size_t plane = (size_t)F.n_streams * m;
     for (uint32_t k = tid; k < 3u * mb; k += kBlock) {
         const uint32_t c = k / mb, p = k - c * mb;
@@ -967,6 +1208,28 @@ void launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const FrameParam
     // 1024) shade every material in place instead.
     const size_t lds_plain = pass_lds_defer_offset(m);
     const size_t lds_defer = lds_plain + (size_t)(kBlock / 64u) * 3u * kDeferCap * sizeof(float4);
+    if (S.cand_scan) {
+        // candidate scan: ray slots, keys and ring per wave, the (smaller) deferral buffers while four workgroups still fit
+        // a CU (40 KiB each; the kernel is built for four waves per SIMD), + the workgroup's copy of the candidate records
+        const size_t budget = 40u * 1024u;
+        const size_t recs = (size_t)S.n_cand_pairs * sizeof(CandPairRec);
+        const bool defer = pass_lds_cand_offset(m, true) + pass_lds_cand_bytes() <= budget;
+        const size_t before = pass_lds_cand_offset(m, defer) + pass_lds_cand_bytes();
+        const bool staged = before + recs <= budget;
+        const size_t lds = before + (staged ? recs : 0u);
+#define PT_LAUNCH_CAND(ST, DF)                                                                                         \
+    hipLaunchKernelGGL((k_pass_cand<ST, DF>), dim3(K), dim3(kBlock), lds, st, S, F, q0, q1, cap, s0, s_here, m, acc, blk_rays, flags)
+        if (staged && defer)
+            PT_LAUNCH_CAND(true, true);
+        else if (staged)
+            PT_LAUNCH_CAND(true, false);
+        else if (defer)
+            PT_LAUNCH_CAND(false, true);
+        else
+            PT_LAUNCH_CAND(false, false);
+#undef PT_LAUNCH_CAND
+        return;
+    }
     if (lds_defer <= 32u * 1024u)
         hipLaunchKernelGGL(k_pass<true>, dim3(K), dim3(kBlock), lds_defer, st, S, F, q0, q1, cap, s0, s_here, m, acc,
                            blk_rays, flags);
