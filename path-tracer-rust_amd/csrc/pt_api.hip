@@ -105,6 +105,7 @@ struct pt_ctx {
     DevBuf<FlatPairRec> d_flat;
     DevBuf<CandPairRec> d_cand;
     DevBuf<uint32_t> d_rank_id;
+    DevBuf<SurfRec> d_surf;
     bool cand_ok = false;
     uint32_t n_bvh_nodes = 0;
     // Mesh.bounding_box of every object (12 object-local triangles each; Mesh::new's unless pt_ctx_set_mesh_bounds gave
@@ -258,7 +259,8 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
     // bounces/s).  A stream owns at most kMaxStreamPixels pixels (their accumulators live in LDS inside k_shade).
     // (scenes with a BVH stage its nodes into LDS once per workgroup: twice the work per stream; mesh.json 2048 streams
     // 7.3, 8192 7.6, 16384 7.0)
-    const uint64_t per_stream = c->scene.n_bvh_nodes != 0u ? 4096u : 2048u;
+    // (candidate scan, four waves per SIMD: 12288 streams 35.8, 16384 35.4, 8192 32.2, 24576 33.7 G bounces/s)
+    const uint64_t per_stream = c->scene.n_bvh_nodes != 0u ? 4096u : (c->scene.cand_scan ? 2688u : 2048u);
     uint64_t k_target = ((uint64_t)npix * spp_pass + per_stream - 1u) / per_stream;
     if (k_target < 2048u) k_target = 2048u;
     if (c->tune.streams) k_target = c->tune.streams;
@@ -599,6 +601,7 @@ void pt_ctx_destroy(pt_ctx *c) {
     c->d_flat.release();
     c->d_cand.release();
     c->d_rank_id.release();
+    c->d_surf.release();
     c->d_boxes.release();
     c->q_o.release();
     c->q_d.release();
@@ -640,7 +643,7 @@ int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uin
         (rc = c->d_mats.ensure(fs.mats.size())) || (rc = c->d_tshade.ensure(fs.tri_shade.size())) ||
         (rc = c->d_nodes.ensure(fs.bvh_nodes.size())) || (rc = c->d_sph.ensure(fs.sph_pairs.size())) ||
         (rc = c->d_flat.ensure(fs.flat_pairs.size())) || (rc = c->d_cand.ensure(fs.cand_pairs.size())) ||
-        (rc = c->d_rank_id.ensure(fs.rank_id.size())))
+        (rc = c->d_rank_id.ensure(fs.rank_id.size())) || (rc = c->d_surf.ensure(fs.surf.size())))
         return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (!fs.objs.empty())
@@ -669,7 +672,9 @@ int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uin
     c->scene.sph_pairs = c->d_sph.p;
     c->scene.flat_pairs = c->d_flat.p;
     c->scene.cand_pairs = c->d_cand.p;
+    HIP_TRY(hipMemcpy(c->d_surf.p, fs.surf.data(), fs.surf.size() * sizeof(SurfRec), hipMemcpyHostToDevice));
     c->scene.rank_id = c->d_rank_id.p;
+    c->scene.surf = c->d_surf.p;
     c->scene.n_sph_pairs = (uint32_t)fs.sph_pairs.size();
     c->scene.n_flat_pairs = (uint32_t)fs.flat_pairs.size();
     c->scene.n_cand_pairs = (uint32_t)fs.cand_pairs.size();

@@ -137,6 +137,16 @@ struct alignas(16) MatRec {
     uint32_t reflect;                // kDiffuse / kSpecular / kRefract
 };
 
+// Everything the shading step needs about the primitive of one visiting rank (candidate scan: the key of a hit holds
+// the rank), in one 48-byte gather instead of rank -> id -> TriShade -> MatRec: for a triangle its normal, for a sphere
+// its centre; then the object's material as in MatRec.
+struct alignas(16) SurfRec {
+    float vx, vy, vz;  // triangle: va_vb.cross(va_vc).normalize() (mod.rs:605); sphere: position (mod.rs:431)
+    uint32_t kind;     // bits 0-1: reflect type, bit 8: triangle
+    float cr, cg, cb, max_refl;
+    float er, eg, eb, inv_max_refl;
+};
+
 // per-triangle shading record, gathered per lane in shade
 struct alignas(16) TriShade {
     float nx, ny, nz;  // va_vb.cross(va_vc).normalize()  (mod.rs:605)
@@ -166,6 +176,7 @@ struct DevScene {
     const FlatPairRec *flat_pairs;  // FlatPairRec.pair = index into cand_pairs
     const CandPairRec *cand_pairs;  // the pair records of every mesh without a BVH
     const uint32_t *rank_id;        // [n_objs + n_tris]
+    const SurfRec *surf;            // [n_objs + n_tris], by rank
     uint32_t n_sph_pairs, n_flat_pairs, n_cand_pairs;
     uint32_t n_other_pairs;         // cand_pairs [0, n_other_pairs) have no filter: candidates for every ray
     uint32_t cand_scan;             // 1: k_pass uses the candidate scan
@@ -698,6 +709,7 @@ struct CandLds {
     float2 *ray_b;              // [2][64]: direction yz
     uint16_t *queue;            // [kCandQueueCap] ring of this wave: slot | record << 7
     const CandPairRec *staged;  // the workgroup's LDS copy of DevScene.cand_pairs (STAGED), else unused
+    const SurfRec *surf;        // the workgroup's LDS copy of DevScene.surf (STAGED), else DevScene.surf
 };
 constexpr unsigned long long kKeyMiss = 0x7f800000ffffffffull;  // +inf, last rank
 
@@ -975,11 +987,33 @@ __device__ __forceinline__ Surface fetch_surface(const DevScene &S, vec3 o, vec3
     return s;
 }
 
-// One radiance() invocation after its intersect_scene call returned Some (mod.rs:665-789).
+// the same from the record of a visiting rank (candidate scan)
+__device__ __forceinline__ Surface fetch_surface_rank(const SurfRec *surf, vec3 o, vec3 d, float t, uint32_t rank) {
+    const SurfRec r = surf[rank];
+    Surface s;
+    s.x = o + d * t;  // mod.rs:430 / mod.rs:604
+    s.n = (r.kind & 0x100u) ? mk(r.vx, r.vy, r.vz) : normalize(s.x - mk(r.vx, r.vy, r.vz));
+    s.color = mk(r.cr, r.cg, r.cb);
+    s.emission = mk(r.er, r.eg, r.eb);
+    s.max_refl = r.max_refl;
+    s.inv_max_refl = r.inv_max_refl;
+    s.reflect = r.kind & 3u;
+    return s;
+}
+
+// One radiance() invocation after its intersect_scene call returned Some (mod.rs:665-789), given the surface hit.
+template <int MODE = kShadeAll, class Params>
+__device__ __forceinline__ void shade_surface(const Params &F, const PathRay &in, const Surface &sf, ShadeOut &out);
+
 template <int MODE = kShadeAll, class Params>
 __device__ __forceinline__ void shade_hit(const DevScene &S, const Params &F, const PathRay &in, HitRec h,
                                           ShadeOut &out) {
     const Surface sf = fetch_surface(S, in.o, in.d, h);
+    shade_surface<MODE>(F, in, sf, out);
+}
+
+template <int MODE, class Params>
+__device__ __forceinline__ void shade_surface(const Params &F, const PathRay &in, const Surface &sf, ShadeOut &out) {
     out.deferred = false;
     if (MODE == kShadeDeferRefract && sf.reflect == kRefract) {
         out.deferred = true;

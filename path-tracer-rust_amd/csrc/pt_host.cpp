@@ -453,6 +453,24 @@ bool flatten_scene(const pt_camera &cam, const pt_object *objs, uint32_t n_objs,
             }
         }
     }
+    // shading records by rank
+    out.surf.assign(out.rank_id.size(), SurfRec{});
+    for (size_t rk = 0; rk + 1 < out.rank_id.size(); ++rk) {
+        const uint32_t id = out.rank_id[rk];
+        SurfRec &sr = out.surf[rk];
+        uint32_t owner = id;
+        if (id >= n_objs) {
+            const TriShade &ts = out.tri_shade[id - n_objs];
+            sr.vx = ts.nx, sr.vy = ts.ny, sr.vz = ts.nz;
+            owner = ts.owner;
+            sr.kind = 0x100u;
+        }
+        const MatRec &mm = out.mats[owner];
+        if (id < n_objs) sr.vx = mm.px, sr.vy = mm.py, sr.vz = mm.pz;
+        sr.kind |= mm.reflect & 3u;
+        sr.cr = mm.cr, sr.cg = mm.cg, sr.cb = mm.cb, sr.max_refl = mm.max_refl;
+        sr.er = mm.er, sr.eg = mm.eg, sr.eb = mm.eb, sr.inv_max_refl = mm.inv_max_refl;
+    }
     out.sph_pairs.clear();
     out.flat_pairs.clear();
     out.cand_pairs.clear();

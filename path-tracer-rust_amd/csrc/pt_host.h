@@ -24,6 +24,7 @@ struct FlatScene {
     std::vector<FlatPairRec> flat_pairs;
     std::vector<CandPairRec> cand_pairs;  // [0, n_other_pairs): records without a filter
     std::vector<uint32_t> rank_id;
+    std::vector<SurfRec> surf;  // by rank
     uint32_t n_other_pairs = 0;
     bool cand_ok = false;  // the scene can use the candidate scan (no BVH mesh, records numbered in 9 bits)
     uint32_t bvh_pair_base = 0;  // first TriPairRec that is a BVH leaf

@@ -508,10 +508,17 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
         cand.queue = reinterpret_cast<uint16_t *>(wbase + 128u * 32u);
         char *sbase = cbase + pass_lds_cand_bytes();
         cand.staged = reinterpret_cast<const CandPairRec *>(sbase);
-        if (STAGED) {  // the workgroup's own copy of the candidate records
+        cand.surf = S.surf;
+        if (STAGED) {  // the workgroup's own copies of the candidate records and of the shading records
             const uint4 *src = reinterpret_cast<const uint4 *>(S.cand_pairs);
             uint4 *dst = reinterpret_cast<uint4 *>(sbase);
-            for (uint32_t k = tid; k < S.n_cand_pairs * (uint32_t)(sizeof(CandPairRec) / 16u); k += kBlock) dst[k] = src[k];
+            const uint32_t n_rows = S.n_cand_pairs * (uint32_t)(sizeof(CandPairRec) / 16u);
+            for (uint32_t k = tid; k < n_rows; k += kBlock) dst[k] = src[k];
+            const uint4 *src2 = reinterpret_cast<const uint4 *>(S.surf);
+            uint4 *dst2 = dst + n_rows;
+            const uint32_t n_rows2 = (S.n_objs + S.n_tris) * (uint32_t)(sizeof(SurfRec) / 16u);
+            for (uint32_t k = tid; k < n_rows2; k += kBlock) dst2[k] = src2[k];
+            cand.surf = reinterpret_cast<const SurfRec *>(dst2);
         }
     }
     const size_t base = (size_t)b * cap;
@@ -572,12 +579,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
             in.d = mk(a.w, bq.x, bq.y);
             in.thr = mk(bq.z, bq.w, cq.x);
             word = __float_as_uint(cq.y);
-            HitRec h;
-            h.t = cq.z;
-            h.id = __float_as_int(cq.w);
             in.pix = lds_pix[word_pix(word)];
             in.meta = pack_meta(s0 + word_sample(word), word_depth(word), word_branch(word));
-            shade_hit<kShadeRefractOnly>(S, P, in, h, so);
+            const Surface sf = fetch_surface_rank(cand.surf, in.o, in.d, cq.z, __float_as_uint(cq.w));  // (t, rank) as parked
+            shade_surface<kShadeRefractOnly>(P, in, sf, so);
             if (so.emits) add_radiance_lds(lds_acc, m, word_pix(word), so.contrib);
         }
         append(so, word);
@@ -641,9 +646,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
                 so.n_rays = 0;
                 so.emits = false;
                 so.deferred = false;
-                HitRec h;
-                h.t = 0.0f;
-                h.id = -1;
+                float hit_t = 0.0f;
+                uint32_t hit_rank = 0xffffffffu;
                 PathRay pr;
                 pr.o = pr.d = pr.thr = mk(0.0f, 0.0f, 0.0f);
                 if (prev_valid) {
@@ -651,8 +655,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
                     const unsigned long long key = cand.keys[slot];
                     const uint32_t rank = (uint32_t)key;
                     if (rank != 0xffffffffu) {
-                        h.t = __uint_as_float((uint32_t)(key >> 32));
-                        h.id = (int32_t)S.rank_id[rank];
+                        hit_t = __uint_as_float((uint32_t)(key >> 32));
+                        hit_rank = rank;
                         const float4 ra = cand.ray_a[slot];
                         const float2 rb = cand.ray_b[slot];
                         pr.o = mk(ra.x, ra.y, ra.z);
@@ -660,7 +664,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
                         pr.thr = prev_thr;
                         pr.pix = lds_pix[word_pix(prev_word)];
                         pr.meta = pack_meta(s0 + word_sample(prev_word), word_depth(prev_word), word_branch(prev_word));
-                        shade_hit<DEFER ? kShadeDeferRefract : kShadeAll>(S, P, pr, h, so);
+                        const Surface sf = fetch_surface_rank(cand.surf, pr.o, pr.d, hit_t, rank);
+                        shade_surface<DEFER ? kShadeDeferRefract : kShadeAll>(P, pr, sf, so);
                         if (so.emits) add_radiance_lds(lds_acc, m, word_pix(prev_word), so.contrib);
                     }
                 }
@@ -671,7 +676,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
                         const uint32_t e = n_defer + lane_prefix(md);
                         dbuf[e] = make_float4(pr.o.x, pr.o.y, pr.o.z, pr.d.x);
                         dbuf[kCandDeferCap + e] = make_float4(pr.d.y, pr.d.z, pr.thr.x, pr.thr.y);
-                        dbuf[2u * kCandDeferCap + e] = make_float4(pr.thr.z, __uint_as_float(prev_word), h.t, __int_as_float(h.id));
+                        dbuf[2u * kCandDeferCap + e] = make_float4(pr.thr.z, __uint_as_float(prev_word), hit_t, __uint_as_float(hit_rank));
                     }
                     n_defer += (uint32_t)__builtin_popcountll(md);
                 }
@@ -1212,7 +1217,7 @@ void launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const FrameParam
         // candidate scan: ray slots, keys and ring per wave, the (smaller) deferral buffers while four workgroups still fit
         // a CU (40 KiB each; the kernel is built for four waves per SIMD), + the workgroup's copy of the candidate records
         const size_t budget = 40u * 1024u;
-        const size_t recs = (size_t)S.n_cand_pairs * sizeof(CandPairRec);
+        const size_t recs = (size_t)S.n_cand_pairs * sizeof(CandPairRec) + (size_t)(S.n_objs + S.n_tris) * sizeof(SurfRec);
         const bool defer = pass_lds_cand_offset(m, true) + pass_lds_cand_bytes() <= budget;
         const size_t before = pass_lds_cand_offset(m, defer) + pass_lds_cand_bytes();
         const bool staged = before + recs <= budget;
