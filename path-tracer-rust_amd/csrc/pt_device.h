@@ -382,6 +382,47 @@ __device__ __forceinline__ void test_pair_planar(const TriPairRec &tr, f32x2 ox2
     }
 }
 
+// Triangle::intersect (mod.rs:559-592) of one ray against the two triangles of a pair record, with the outcome of each
+// as an integer key instead of a decision: key = (k << 32) | tr.id[half] where k = bits(distance) - 1 for an accepted hit
+// (order and ties of the distances are kept) and >= 0x7fffffff for a rejected one - so that "closest, smallest id among
+// equals" over any number of triangles is one integer minimum (an LDS atomic), with no compare or select instruction.
+//   The five rejections of mod.rs:571-592 are ONE sign bit, built with two-cycle integer instructions instead of
+//   compares and selects (4 cycles each, profiles/r02_valu_issue_costs.json):
+//     u < 0, v < 0, u + v > 1  <=> the sign bit of (u + 0) | (v + 0) | (1 - (u + v)): adding +0 turns a -0 into +0 (the
+//                                  reference keeps u = -0: `u < 0.0` is false), 1 - s is negative exactly when s > 1 (s and
+//                                  1 are floats: the rounded difference has the sign of the real one), and u > 1 is implied
+//                                  by u + v > 1 (test_pair).  NaN cannot occur with |det| >= 1e-4;
+//     |det| < 1e-4             <=> (bits(det) & 0x7fffffff) - bits(1e-4) is negative as an integer.
+//   The bit is OR-ed into the bits of the distance; k = bits - 1 then maps distance > 0 to [0, 0x7f7ffffe], +0 to
+//   0xffffffff and anything negative, -0 or rejected to >= 0x7fffffff.
+template <class Rec>
+__device__ __forceinline__ void pair_test_keys(const Rec &tr, vec3 ro, vec3 rd, unsigned long long keys2[2], float t_hit[2]) {
+    const f32x2 ox2 = splat2(ro.x), oy2 = splat2(ro.y), oz2 = splat2(ro.z);
+    const f32x2 dx2 = splat2(rd.x), dy2 = splat2(rd.y), dz2 = splat2(rd.z);
+    const f32x2 e1x = ld2(tr.e1x), e1y = ld2(tr.e1y), e1z = ld2(tr.e1z);
+    const f32x2 e2x = ld2(tr.e2x), e2y = ld2(tr.e2y), e2z = ld2(tr.e2z);
+    const f32x2 px = dy2 * e2z - e2y * dz2, py = dz2 * e2x - e2z * dx2, pz = dx2 * e2y - e2x * dy2;
+    const f32x2 determinant = (e1x * px + e1y * py) + e1z * pz;
+    const f32x2 inv_det = f_rcp2(determinant);
+    const f32x2 tx = ox2 - ld2(tr.ax), ty = oy2 - ld2(tr.ay), tz = oz2 - ld2(tr.az);
+    const f32x2 u = ((tx * px + ty * py) + tz * pz) * inv_det;
+    const f32x2 qx = ty * e1z - e1y * tz, qy = tz * e1x - e1z * tx, qz = tx * e1y - e1x * ty;
+    const f32x2 v = ((dx2 * qx + dy2 * qy) + dz2 * qz) * inv_det;
+    const f32x2 dist = ((e2x * qx + e2y * qy) + e2z * qz) * inv_det;
+    const f32x2 zero = splat2(0.0f);
+    const f32x2 s_uv = (u + zero) + (v + zero);
+    const f32x2 w = splat2(1.0f) - s_uv;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        const uint32_t ub = __float_as_uint(u[hf] + 0.0f), vb = __float_as_uint(v[hf] + 0.0f), wb = __float_as_uint(w[hf]);
+        const uint32_t db = (__float_as_uint(determinant[hf]) & 0x7fffffffu) - 0x38d1b717u;  // bits(1e-4f)
+        const uint32_t bad = (ub | vb | wb | db) & 0x80000000u;
+        const uint32_t k = (__float_as_uint(dist[hf]) | bad) - 1u;
+        keys2[hf] = ((unsigned long long)k << 32) | tr.id[hf];
+        t_hit[hf] = dist[hf];
+    }
+}
+
 // Slab test of the two (padded) child boxes of a node at once: packed fma/min/max, NaN-ignoring min/max (a
 // slab whose bounds come out NaN - ray parallel to it and 0*inf - simply does not constrain).  This test only
 // has to be conservative, not bit-identical to anything: the boxes are padded by the worst-case error of the
@@ -488,6 +529,121 @@ __device__ __forceinline__ void bvh_closest(const DevScene &S, NodePtr nodes, Co
     }
 }
 
+// bvh_closest with the LEAVES POSTPONED.  In bvh_closest a lane that reaches a leaf waits until enough others have (the
+// quorum) and the triangle code - by far the longest part of a step - then runs for those lanes only: the walks ran at
+// 17 of 64 lanes.  Here a lane that reaches a leaf only appends (lane, leaf) to a per-wave list in LDS and moves on to the
+// next entry of its stack; whenever the list holds as many entries as the wave has walking lanes, the wave runs one
+// DENSE batch of leaf tests: lane e fetches entry e's ray from its owner's registers (ds_bpermute), gathers the leaf's pair
+// record, evaluates both triangles (pair_test_keys: the reference's arithmetic, outcome as integer keys) and folds them
+// into the owner's key with two LDS atomic minima - key = (distance bits - 1) << 32 | triangle index: the closest, the
+// smaller index among equal distances, exactly test_pair<false>'s rule, whatever the order.  After a batch every lane
+// refreshes its pruning bound from its key.  Called by the walking lanes of a wave together (any subset of the wave).
+// A key is written by other lanes of the wave (LDS atomic minima) and read back by its owner: the read has to be an atomic
+// load - a plain one may be satisfied from the value the owner itself stored last (the compiler sees no other writer).
+__device__ __forceinline__ unsigned long long load_key(const unsigned long long *p) {
+    return __atomic_load_n(p, __ATOMIC_RELAXED);
+}
+
+struct LeafLds {
+    unsigned long long *keys;  // [64] of this wave
+    uint32_t *list;            // [kLeafListCap] of this wave: lane | leaf pair record << 6
+};
+constexpr uint32_t kLeafListCap = 192;  // < 64 left over + 64 appended by one step
+
+template <class NodePtr, class Codec>
+__device__ __forceinline__ void bvh_closest_postponed(const DevScene &S, NodePtr nodes, Codec codec, typename Codec::T *stack,
+                                                      uint32_t stride, const LeafLds &L, vec3 o, vec3 d, int32_t root,
+                                                      float best_t, float &mt, int32_t &mid) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t act = __builtin_amdgcn_ballot_w64(true);
+    const uint32_t n_act = (uint32_t)__builtin_popcountll(act);
+    const uint32_t my = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+    L.keys[lane] = ~0ull;
+    const float big = 1e18f;  // see bvh_closest
+    const vec3 inv = mk(__builtin_fmaxf(__builtin_fminf(1.0f / d.x, big), -big),
+                        __builtin_fmaxf(__builtin_fminf(1.0f / d.y, big), -big),
+                        __builtin_fmaxf(__builtin_fminf(1.0f / d.z, big), -big));
+    const f32x2 ivx = splat2(inv.x), ivy = splat2(inv.y), ivz = splat2(inv.z);
+    const f32x2 oix = splat2(o.x * inv.x), oiy = splat2(o.y * inv.y), oiz = splat2(o.z * inv.z);
+    constexpr int32_t kDone = (int32_t)0x80000000;
+    uint32_t n_leaf = 0;   // wave-uniform
+    float bound = best_t;  // min(best of the other objects, this lane's best triangle so far)
+    auto leaf_batch = [&](uint32_t base, uint32_t count) {  // list entries [base, base + count), count <= n_act
+        const bool valid = my < count;
+        const uint32_t ent = valid ? L.list[base + my] : lane;
+        const int sel = (int)((ent & 63u) << 2);
+        vec3 ro, rd;
+        ro.x = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(o.x)));
+        ro.y = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(o.y)));
+        ro.z = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(o.z)));
+        rd.x = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(d.x)));
+        rd.y = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(d.y)));
+        rd.z = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(d.z)));
+        if (valid) {
+            const TriPairRec tr = S.tri_pairs[ent >> 6];
+            unsigned long long k2[2];
+            float th[2];
+            pair_test_keys(tr, ro, rd, k2, th);
+            atomicMin(&L.keys[ent & 63u], k2[0]);
+            atomicMin(&L.keys[ent & 63u], k2[1]);
+        }
+    };
+    uint32_t sp = 0;
+    int32_t cur = root;
+    for (;;) {  // wave-uniform loop: every lane that still has work takes one step per trip
+        if (__builtin_amdgcn_ballot_w64(cur != kDone) == 0ull) break;
+        bool at_leaf = false;
+        uint32_t leaf = 0;
+        if (cur >= 0) {
+            const BvhNode n = nodes[cur];
+            bool h0, h1;
+            f32x2 tin;
+            hit_boxes(n, ivx, ivy, ivz, oix, oiy, oiz, bound, &h0, &h1, &tin);
+            if (h0 && h1) {
+                const bool first0 = tin[0] <= tin[1];
+                if (sp < kBvhStack) stack[sp * stride] = codec.enc(first0 ? n.c[1] : n.c[0]);
+                ++sp;  // (the host guarantees tree depth < kBvhStack)
+                cur = first0 ? n.c[0] : n.c[1];
+            } else if (h0 || h1) {
+                cur = h0 ? n.c[0] : n.c[1];
+            } else if (sp != 0u) {
+                --sp;
+                cur = codec.dec(stack[sp * stride]);
+            } else {
+                cur = kDone;
+            }
+        } else if (cur != kDone) {
+            at_leaf = true;
+            leaf = (uint32_t)~cur;
+            if (sp == 0u) {
+                cur = kDone;
+            } else {
+                --sp;
+                cur = codec.dec(stack[sp * stride]);
+            }
+        }
+        const uint64_t ml = __builtin_amdgcn_ballot_w64(at_leaf);
+        if (ml != 0ull) {
+            if (at_leaf)
+                L.list[n_leaf + __builtin_amdgcn_mbcnt_hi((uint32_t)(ml >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ml, 0u))] = lane | (leaf << 6);
+            n_leaf += (uint32_t)__builtin_popcountll(ml);
+            while (n_leaf >= n_act) {
+                n_leaf -= n_act;
+                leaf_batch(n_leaf, n_act);
+                const uint32_t k = (uint32_t)(load_key(&L.keys[lane]) >> 32);
+                if (k < 0x7f800000u) bound = __builtin_fminf(best_t, __uint_as_float(k + 1u));
+            }
+        }
+    }
+    if (n_leaf != 0u) leaf_batch(0u, n_leaf);
+    const unsigned long long key = load_key(&L.keys[lane]);
+    const uint32_t k = (uint32_t)(key >> 32);
+    if (k < 0x7f800000u) {
+        mt = __uint_as_float(k + 1u);
+        mid = (int32_t)(uint32_t)key;
+    }
+}
+
 // LDS carve-up of the kernels that intersect: [BvhNode x n_bvh_nodes][u16 stack: kBvhStack x blockDim] when the
 // nodes are staged, else [u32 stack: kBvhStack x blockDim] alone (nodes read from global memory)
 __device__ __forceinline__ void stage_bvh(const DevScene &S, uint4 *lds) {
@@ -506,8 +662,20 @@ __host__ __device__ inline size_t bvh_lds_bytes(const DevScene &S, uint32_t bloc
 #if defined(__HIPCC__)
 // one lane's walk of one mesh, with the node storage and stack width the scene was set up for
 __device__ __forceinline__ void bvh_walk(const DevScene &S, uint4 *lds, vec3 o, vec3 d, int32_t root, float best_t,
-                                         float &mt, int32_t &mid) {
+                                         float &mt, int32_t &mid, const LeafLds *leaves = nullptr) {
     uint4 *const stacks = (S.bvh_in_lds & 1u) ? lds + S.n_bvh_nodes * 4u : lds;
+    if (leaves) {  // k_pass_bvh: nodes in global memory, leaves postponed
+        if (S.bvh_in_lds & 2u) {
+            Stack16 codec;
+            codec.pair_base = S.bvh_pair_base;
+            bvh_closest_postponed(S, S.bvh_nodes, codec, reinterpret_cast<uint16_t *>(stacks) + threadIdx.x, blockDim.x, *leaves,
+                                  o, d, root, best_t, mt, mid);
+        } else {
+            bvh_closest_postponed(S, S.bvh_nodes, Stack32(), reinterpret_cast<uint32_t *>(stacks) + threadIdx.x, blockDim.x,
+                                  *leaves, o, d, root, best_t, mt, mid);
+        }
+        return;
+    }
     if (S.bvh_in_lds & 2u) {
         uint16_t *stack = reinterpret_cast<uint16_t *>(stacks) + threadIdx.x;
         Stack16 codec;
@@ -788,44 +956,9 @@ __device__ __forceinline__ void cand_batch(const DevScene &S, const CandLds &L, 
             tr = L.staged[q];  // per-lane gather from LDS
         else
             tr = S.cand_pairs[q];
-        // Triangle::intersect's arithmetic for both triangles of the record (mod.rs:559-589), as in test_pair
-        const f32x2 ox2 = splat2(ro.x), oy2 = splat2(ro.y), oz2 = splat2(ro.z);
-        const f32x2 dx2 = splat2(rd.x), dy2 = splat2(rd.y), dz2 = splat2(rd.z);
-        const f32x2 e1x = ld2(tr.e1x), e1y = ld2(tr.e1y), e1z = ld2(tr.e1z);
-        const f32x2 e2x = ld2(tr.e2x), e2y = ld2(tr.e2y), e2z = ld2(tr.e2z);
-        const f32x2 px = dy2 * e2z - e2y * dz2, py = dz2 * e2x - e2z * dx2, pz = dx2 * e2y - e2x * dy2;
-        const f32x2 determinant = (e1x * px + e1y * py) + e1z * pz;
-        const f32x2 inv_det = f_rcp2(determinant);
-        const f32x2 tx = ox2 - ld2(tr.ax), ty = oy2 - ld2(tr.ay), tz = oz2 - ld2(tr.az);
-        const f32x2 u = ((tx * px + ty * py) + tz * pz) * inv_det;
-        const f32x2 qx = ty * e1z - e1y * tz, qy = tz * e1x - e1z * tx, qz = tx * e1y - e1x * ty;
-        const f32x2 v = ((dx2 * qx + dy2 * qy) + dz2 * qz) * inv_det;
-        const f32x2 dist = ((e2x * qx + e2y * qy) + e2z * qz) * inv_det;
-        // The five rejections of mod.rs:571-592 as ONE sign bit per triangle, built with two-cycle integer instructions
-        // instead of compares and selects (4 cycles each, profiles/r02_valu_issue_costs.json):
-        //   u < 0, v < 0, u + v > 1   <=> the sign bit of (u + 0) | (v + 0) | (1 - (u + v)): adding +0 turns a -0 into
-        //                                 +0 (the reference keeps u = -0: `u < 0.0` is false), 1 - s is negative exactly
-        //                                 when s > 1 (s, 1 are floats: the difference has the sign of the real one), and
-        //                                 u > 1 is implied by u + v > 1 (test_pair).  NaN cannot occur with |det| >= 1e-4;
-        //   |det| < 1e-4              <=> (bits(det) & 0x7fffffff) - bits(1e-4) is negative as an integer.
-        // A rejected triangle gets the sign bit OR-ed into the bits of its distance; k = bits - 1 then maps
-        //   distance > 0 (accepted)  ->  bits - 1 in [0, 0x7f7fffff]: order and ties of the distances are kept,
-        //   +0                       ->  0xffffffff,   negative / -0 / rejected  ->  >= 0x7fffffff,
-        // all three above every accepted value and above the "no hit" key 0x7f800000 - 1, so they never win.
-        const f32x2 zero = splat2(0.0f);
-        const f32x2 s_uv = (u + zero) + (v + zero);
-        const f32x2 w = splat2(1.0f) - s_uv;
         unsigned long long keys2[2];
         float t_hit[2];
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            const uint32_t ub = __float_as_uint(u[hf] + 0.0f), vb = __float_as_uint(v[hf] + 0.0f), wb = __float_as_uint(w[hf]);
-            const uint32_t db = (__float_as_uint(determinant[hf]) & 0x7fffffffu) - 0x38d1b717u;  // bits(1e-4f)
-            const uint32_t bad = (ub | vb | wb | db) & 0x80000000u;
-            const uint32_t k = (__float_as_uint(dist[hf]) | bad) - 1u;
-            keys2[hf] = ((unsigned long long)k << 32) | tr.id[hf];
-            t_hit[hf] = dist[hf];
-        }
+        pair_test_keys(tr, ro, rd, keys2, t_hit);
         // the mesh's gate (mod.rs:267-273), for the nearer accepted triangle of the record (a gate that fails rejects
         // both: it depends on the ray and the mesh only).  Usually the hit point lies well inside the bounding sphere
         // (ObjRec.rr_in: then the f32 gate cannot fail); otherwise intersect_sphere(...).is_some() as the reference does.
@@ -900,7 +1033,7 @@ __device__ __forceinline__ void cand_filter_and_drain(const DevScene &S, const C
 // visiting order, exact gate first.  A triangle strictly closer than the best so far wins; one exactly as far would
 // need the reference's visiting order to decide - reported, and the caller repeats that ray with the in-order scan.
 __device__ __forceinline__ bool walk_deferred(const DevScene &S, vec3 o, vec3 d, uint4 *lds, float &best_t,
-                                              int32_t &best_id) {
+                                              int32_t &best_id, const LeafLds *leaves = nullptr) {
     bool tie = false;
     const uint32_t n_pairs = (S.n_objs + 1u) >> 1;
     for (uint32_t p = 0; p < n_pairs; ++p) {
@@ -918,7 +1051,7 @@ __device__ __forceinline__ bool walk_deferred(const DevScene &S, vec3 o, vec3 d,
             float mt = __builtin_inff();
             int32_t mid = -1;
             if (pass) {
-                bvh_walk(S, lds, o, d, root, best_t, mt, mid);
+                bvh_walk(S, lds, o, d, root, best_t, mt, mid, leaves);
             }
             if (pass && mid >= 0) {
                 if (mt < best_t) {

@@ -652,7 +652,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
                 pr.o = pr.d = pr.thr = mk(0.0f, 0.0f, 0.0f);
                 if (prev_valid) {
                     const uint32_t slot = ((par ^ 1u) << 6) | lane;
-                    const unsigned long long key = cand.keys[slot];
+                    const unsigned long long key = load_key(&cand.keys[slot]);
                     const uint32_t rank = (uint32_t)key;
                     if (rank != 0xffffffffu) {
                         hit_t = __uint_as_float((uint32_t)(key >> 32));
@@ -720,8 +720,12 @@ __host__ __device__ inline size_t pass_bvh_park_offset(const DevScene &S, uint32
     return (pass_bvh_stack_offset(m) + (size_t)kBvhStack * kBlock * ((S.bvh_in_lds & 2u) ? sizeof(uint16_t) : sizeof(uint32_t)) + 15) &
            ~(size_t)15;
 }
+// after the parking areas: per wave [u64 key: 64][u32 leaf list: kLeafListCap] of the postponed leaf tests
+__host__ __device__ inline size_t pass_bvh_leaf_offset(const DevScene &S, uint32_t m) {
+    return (pass_bvh_park_offset(S, m) + (size_t)(kBlock / 64u) * kPassParkCap * 12u + 15) & ~(size_t)15;
+}
 __host__ __device__ inline size_t pass_bvh_lds_bytes(const DevScene &S, uint32_t m) {
-    return pass_bvh_park_offset(S, m) + (size_t)(kBlock / 64u) * kPassParkCap * 12u;
+    return pass_bvh_leaf_offset(S, m) + (size_t)(kBlock / 64u) * (64u * 8u + kLeafListCap * 4u);
 }
 
 __global__ __launch_bounds__(kBlock, 5) void k_pass_bvh(DevScene S, FrameParams F, RayQueue q0, RayQueue q1, uint32_t cap,
@@ -744,6 +748,12 @@ __global__ __launch_bounds__(kBlock, 5) void k_pass_bvh(DevScene S, FrameParams 
     uint32_t *const p_idx = reinterpret_cast<uint32_t *>(park);
     float *const p_t = reinterpret_cast<float *>(p_idx + kPassParkCap);
     int32_t *const p_id = reinterpret_cast<int32_t *>(p_t + kPassParkCap);
+    LeafLds leaves;
+    {
+        char *lbase = reinterpret_cast<char *>(dyn_lds) + pass_bvh_leaf_offset(S, m) + (size_t)(tid >> 6) * (64u * 8u + kLeafListCap * 4u);
+        leaves.keys = reinterpret_cast<unsigned long long *>(lbase);
+        leaves.list = reinterpret_cast<uint32_t *>(lbase + 64u * 8u);
+    }
     const size_t base = (size_t)b * cap;
     ShadeParams P;
     P.idx_begin = F.idx_begin;
@@ -825,7 +835,8 @@ __global__ __launch_bounds__(kBlock, 5) void k_pass_bvh(DevScene S, FrameParams 
             load_ray(p_idx[e], in, word);
             h.t = p_t[e];
             h.id = p_id[e];
-            if (walk_deferred(S, in.o, in.d, stacks, h.t, h.id)) h = scan_scene<true, true>(S, in.o, in.d, stacks);
+            if (walk_deferred(S, in.o, in.d, stacks, h.t, h.id, &leaves))
+                h = scan_scene<true, true>(S, in.o, in.d, stacks);
         }
         shade_and_append(valid, in, word, h);
     };
