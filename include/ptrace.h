@@ -179,6 +179,11 @@ int pt_device_download(int device, void *dst_host, const void *src_device, size_
 
 /* Enable HIP-event timing of every launch of the dominant kernel (fills pt_stats.ms_intersect). */
 int pt_ctx_set_profiling(pt_ctx *ctx, int enabled);
+/* Name of the kernel the wavefront backend launches for this context's scene with these pt_config.flags - the one
+ * pt_stats.intersect_launches / ms_intersect describe: "k_pass_cand" (one launch per pass, candidate scan: scenes
+ * without BVH meshes), "k_pass" (the same with every triangle tested per ray), "k_pass_bvh", or "k_intersect" (separate
+ * kernels).  For profilers and bench.py; NULL without a scene. */
+const char *pt_ctx_pass_kernel(const pt_ctx *ctx, uint32_t flags);
 
 /* Single-ray queries through the same device intersection code (a6): the callers are object
  * picking / click-debug / orbit pivot (src/views/viewport_tab.rs:240-246, render_tab.rs:177-205).

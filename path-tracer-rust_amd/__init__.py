@@ -76,6 +76,8 @@ def lib():
     L.pt_ctx_render.argtypes = [C.c_void_p, C.POINTER(pt_config), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.POINTER(pt_stats)]
     L.pt_ctx_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.pt_ctx_pass_kernel.argtypes = [C.c_void_p, C.c_uint32]
+    L.pt_ctx_pass_kernel.restype = C.c_char_p
     L.pt_scene_load.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
     L.pt_scene_free.argtypes = [C.c_void_p]
     L.pt_scene_free.restype = None
@@ -142,6 +144,11 @@ class Context:
     def set_scene(self, scene):
         _check(lib().pt_ctx_set_scene(self._h, scene.camera, scene.objects, scene.n_objects, scene.triangles,
                                       scene.n_triangles))
+
+    def pass_kernel(self, separate_kernels=False):
+        """Name of the kernel a wavefront pass of this scene launches (see pt_ctx_pass_kernel)."""
+        n = lib().pt_ctx_pass_kernel(self._h, PT_FLAG_SEPARATE_KERNELS if separate_kernels else 0)
+        return n.decode() if n else None
 
     def set_profiling(self, on):
         _check(lib().pt_ctx_set_profiling(self._h, 1 if on else 0))

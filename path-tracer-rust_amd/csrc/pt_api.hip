@@ -746,6 +746,17 @@ int pt_device_download(int device, void *dst_host, const void *src_device, size_
     return PT_OK;
 }
 
+const char *pt_ctx_pass_kernel(const pt_ctx *c, uint32_t flags) {
+    if (!c || !c->has_scene) return nullptr;
+    const bool no_bvh = (flags & PT_FLAG_NO_BVH) != 0u;
+    const uint32_t n_nodes = no_bvh ? 0u : c->n_bvh_nodes;
+    const bool bvh_ok = n_nodes == 0u || (!(c->scene.bvh_in_lds & 1u) && c->tune.pass_bvh);
+    const bool one_kernel = bvh_ok && c->tune.pass_kernel && !(flags & PT_FLAG_SEPARATE_KERNELS);
+    if (!one_kernel) return "k_intersect";
+    if (n_nodes != 0u) return "k_pass_bvh";
+    return (c->tune.cand_scan && c->cand_ok && !no_bvh) ? "k_pass_cand" : "k_pass";
+}
+
 int pt_ctx_set_profiling(pt_ctx *c, int enabled) {
     if (!c) {
         set_error("ctx is NULL");

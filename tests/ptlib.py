@@ -172,6 +172,8 @@ def product():
     L.pt_ctx_render.argtypes = [C.c_void_p, C.POINTER(PtConfig), C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.POINTER(PtStats)]
     L.pt_ctx_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.pt_ctx_pass_kernel.argtypes = [C.c_void_p, C.c_uint32]
+    L.pt_ctx_pass_kernel.restype = C.c_char_p
     L.pt_render_multi.argtypes = [C.POINTER(PtConfig), C.c_uint32, C.POINTER(PtCamera), C.POINTER(PtObject), C.c_uint32,
                                   C.POINTER(PtTriangle), C.c_uint32, fp, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.POINTER(PtStats)]

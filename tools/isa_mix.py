@@ -33,6 +33,28 @@ def classify(op, operands):
     return "B"
 
 
+def mix(path, name):
+    """Static class counts of the first kernel of `path` whose symbol contains `name`: {"A":…, "B":…, "C":…, "valu":…,
+    "avg_cost": additive cycles per VALU instruction} - or None when the kernel is not in the listing."""
+    in_kernel = False
+    tot = {"A": 0, "B": 0, "C": 0}
+    for line in open(path):
+        line = line.split(";")[0].rstrip()
+        if not in_kernel:
+            if re.match(r"^[\w.$]+:", line) and name in line and not line.startswith(".L"):
+                in_kernel = True
+            continue
+        if line.strip().startswith("s_endpgm"):
+            break
+        m = re.match(r"^\s+([a-z_0-9]+)\s*(.*)$", line)
+        if m and m.group(1).startswith("v_"):
+            tot[classify(m.group(1), m.group(2))] += 1
+    n = sum(tot.values())
+    if not in_kernel or n == 0:
+        return None
+    return dict(tot, valu=n, avg_cost=(2 * tot["A"] + 4 * tot["B"] + 8 * tot["C"]) / n)
+
+
 def main():
     path, name = sys.argv[1], sys.argv[2]
     per_block = "--blocks" in sys.argv

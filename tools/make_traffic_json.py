@@ -1,14 +1,18 @@
 #!/usr/bin/env python3
-"""Turn the three PMC passes of tools/pmc_run.sh <tag> into profiles/<tag>_pmc_<what>.json and
-profiles/r01_intersect_traffic.json (read by bench.py for roofline.traffic).
+"""Turn the three PMC passes of tools/pmc_run.sh <tag> into profiles/<tag>_pmc_<what>.json and, per dominant kernel,
+profiles/r02_<kernel>_traffic.json (read by bench.py for roofline.traffic and for the VALU issue figure):
+  hbm_bytes_per_ray   (2 x FETCH_SIZE + WRITE_SIZE) / rays - the gfx950 correction of MI355X_MICROARCH.md's HBM section
+  valu                dynamic VALU wave-instructions per ray x 64 (SQ_INSTS_VALU), VALU busy (SQ_ACTIVE_INST_VALU /
+                      SQ_BUSY_CYCLES / 8), and the kernel's static issue-class mix (tools/isa_mix.py over
+                      path-tracer-rust_amd/pt_kernels.s, classes priced by profiles/r02_valu_issue_costs.json)
 usage: python tools/make_traffic_json.py <tag> <what, e.g. cornell_1024x768_128spp> "<bench args of the run>" """
 import json
 import os
-import re
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from pmc_summary import summarise
+import isa_mix
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, what, bench_args = sys.argv[1], sys.argv[2], sys.argv[3]
@@ -24,17 +28,25 @@ def kernel(d, frag):
     return next((v for k, v in d.items() if frag in k), None)
 
 
-NOTE = ("SQ_INSTS_VALU x 64 / rays; SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES / 8 (8 = all 32 SIMDs of a shader engine issuing "
-        "a VALU instruction every quad-cycle): the kernel is bound by VALU instruction issue, not by HBM")
+NOTE = ("insts_per_ray = SQ_INSTS_VALU x 64 / rays (dynamic); busy_frac = SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES / 8; "
+        "static_mix = instruction classes of the kernel's ISA (A: 2 cycles per wave-instruction per SIMD, B: 4, C: 8 - "
+        "measured, profiles/r02_valu_issue_costs.json; the classes add up in real code: tools/valu_issue_bench.hip "
+        "and the no-packed-instruction A/B of DESIGN section 4); avg_cost = sum(count x cost) / count")
+ASM = os.path.join(ROOT, "path-tracer-rust_amd", "pt_kernels.s")
+# kernel name in the profile -> symbol fragment in the listing (most specific first)
+KERNELS = [("k_pass_cand", "k_pass_candILb1ELb1"), ("k_pass_bvh", "k_pass_bvhE"), ("k_pass<", "k_passILb1"),
+           ("k_intersect", "k_intersectILb0"), ("k_mega", "k_megaILb0")]
 done = {}
-for kname in ("k_pass", "k_intersect", "k_shade"):
+for kname, sym in KERNELS:
     sq = kernel(out["sq"], kname)
     if sq is None:
         continue
     fetch = kernel(out["fetch"], kname)["FETCH_SIZE"] * 1024.0  # counter is in KiB
     write = kernel(out["write"], kname)["WRITE_SIZE"] * 1024.0
+    clean = kname.rstrip("<")
+    static = isa_mix.mix(ASM, sym) if os.path.exists(ASM) else None
     tr = {
-        "kernel": kname,
+        "kernel": clean,
         "rays": rays,
         "dispatches": sq["dispatches"],
         "FETCH_SIZE_bytes": fetch,
@@ -43,15 +55,15 @@ for kname in ("k_pass", "k_intersect", "k_shade"):
         "correction": "FETCH_SIZE x2 (gfx950 tallies 128-B requests of wide coalesced reads at 64 B, "
                       "MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported; both in KiB",
         "source": "profiles/%s: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py "
-                  "--steps 1 --warmup 0 %s`" % (name, bench_args),
+                  "--steps 1 --warmup 0 --no-cpu-baseline --no-variants %s`" % (name, bench_args),
         "valu": {
             "insts_per_ray": sq["SQ_INSTS_VALU"] * 64.0 / rays,
             "busy_frac": sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_BUSY_CYCLES"] / 8.0,
+            "static_mix": static,
             "note": NOTE,
         },
     }
-    done[kname] = tr
-    if kname != "k_shade":  # bench.py reads r01_<dominant kernel>_traffic.json
-        with open(os.path.join(ROOT, "profiles", "r01_%s_traffic.json" % kname), "w") as f:
-            json.dump(tr, f, indent=1)
+    done[clean] = tr
+    with open(os.path.join(ROOT, "profiles", "r02_%s_traffic.json" % clean), "w") as f:
+        json.dump(tr, f, indent=1)
 print(json.dumps(done, indent=1))
