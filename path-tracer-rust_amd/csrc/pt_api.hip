@@ -127,6 +127,10 @@ struct pt_ctx {
     // state of the frame being rendered (for pt_ctx_snapshot from the progress callback)
     uint32_t live_npix = 0, live_spp_issued = 0, live_streams = 1, live_m = 0;
     hipStream_t live_stream = nullptr;
+    // a large call is rendered in parts: pixels [0, live_k0) of it are final in live_out, [live_k0, live_k0 + live_npix) are
+    // the part in progress, the rest has not been started (live_total pixels in all)
+    float *live_out = nullptr;
+    uint32_t live_k0 = 0, live_total = 0;
     // concurrent pipelines (PT_FLAG_PIPELINES): child contexts that borrow this context's scene tables
     std::vector<pt_ctx *> pipes;
     std::vector<DevBuf<float>> pipe_out;
@@ -219,6 +223,7 @@ FrameParams make_frame(const pt_ctx *ctx, const pt_config *cfg, uint32_t idx_beg
     F.sv_y = sv[1];
     F.sv_z = sv[2];
     F.debug = ctx->tune.debug;
+    F.k_begin = 0;
     return F;
 }
 
@@ -877,38 +882,85 @@ int pt_ctx_render(pt_ctx *c, const pt_config *cfg, void *d_out_rgb, void *hip_st
     const FrameParams F = make_frame(c, cfg, ib, ie);
     if (stats) memset(stats, 0, sizeof *stats);
     if (F.npix == 0u) return PT_OK;  // this rank owns no chunk of the band
-    c->live_npix = F.npix;
-    c->live_spp_issued = 0;
-    c->live_stream = st;
     // PT_FLAG_NO_BVH: scan meshes triangle by triangle as the reference does (same result, for A/B checks)
     c->scene.n_bvh_nodes = (cfg->flags & PT_FLAG_NO_BVH) ? 0u : c->n_bvh_nodes;
     c->scene.planar = (cfg->flags & PT_FLAG_NO_BVH) ? 0u : 1u;
     c->scene.cand_scan = (c->tune.cand_scan && c->cand_ok && !(cfg->flags & PT_FLAG_NO_BVH)) ? 1u : 0u;
     const double t0 = now_ms();
-    if (cfg->backend == PT_BACKEND_WAVEFRONT)
-        rc = render_wavefront(c, cfg, F, st, cancel, cb, user, stats);
-    else
-        rc = render_mega(c, cfg, F, st, cancel, cb, user, stats);
-    if (rc == PT_OK || rc == PT_CANCELLED) {
-        // A cancelled frame resolves what was accumulated by the samples per pixel that were accumulated
-        // (live_spp_issued, also reported through stats->samples): every pixel at full brightness over fewer samples -
-        // the same picture pt_ctx_snapshot gives.  (The reference's partial image has finished pixels at full spp and the
-        // rest black, mod.rs:1003-1016; a GPU pass covers every pixel, so "fewer samples everywhere" is its counterpart.)
-        // Nothing accumulated yet: all zero, as the reference's untouched `pixels` vector.
-        const uint32_t spp_done = rc == PT_OK ? cfg->spp : c->live_spp_issued;
-        if (spp_done != 0u)
-            launch_resolve(st, c->acc.p, (float *)d_out_rgb, F.npix, spp_done, c->live_streams, c->live_m);
+    // Parts.  The wavefront kernels are tuned for streams of a few dozen pixels with a couple of thousand rays per pass
+    // (accumulators, ray slots and deferral buffers share 40 KB of LDS per workgroup); a call of many millions of pixels
+    // (4096^2: BASELINE config 5) would need streams of 1024 pixels or passes of hundreds of GB.  Such a call is
+    // rendered as consecutive parts of about a million call-local pixels, each exactly like a frame of that size - the
+    // RNG is keyed on the global pixel index, so the image is the same bits.  Progress counts finished parts; a
+    // cancelled call leaves the parts it did not start black (the reference's unrendered pixels are black too,
+    // mod.rs:1003-1016) and the part in progress averaged over its accumulated samples.
+    const uint32_t total = F.npix;
+    const bool in_parts = cfg->backend == PT_BACKEND_WAVEFRONT && total > (3u << 19);
+    const uint32_t part_px = in_parts ? (1u << 20) : total;
+    const uint32_t n_parts = (total + part_px - 1u) / part_px;
+    struct Relay {
+        pt_progress_fn cb;
+        void *user;
+        float base, scale;
+        static void fn(void *self, float f) {
+            Relay *r = (Relay *)self;
+            if (f < 1.0f) r->cb(r->user, r->base + r->scale * f);  // a part's completion is reported by the next part / the end
+        }
+    } relay{cb, user, 0.0f, 1.0f / (float)n_parts};
+    c->live_out = (float *)d_out_rgb;
+    c->live_total = total;
+    c->live_stream = st;
+    rc = PT_OK;
+    for (uint32_t part = 0; part < n_parts && rc == PT_OK; ++part) {
+        FrameParams Fp = F;
+        Fp.k_begin = part * part_px;
+        Fp.npix = (total - Fp.k_begin) < part_px ? (total - Fp.k_begin) : part_px;
+        float *out_p = (float *)d_out_rgb + (size_t)Fp.k_begin * 3;
+        c->live_k0 = Fp.k_begin;
+        c->live_npix = Fp.npix;
+        c->live_spp_issued = 0;
+        relay.base = (float)part / (float)n_parts;
+        pt_stats ps;
+        memset(&ps, 0, sizeof ps);
+        pt_progress_fn part_cb = cb ? (n_parts > 1u ? &Relay::fn : cb) : nullptr;
+        void *part_user = n_parts > 1u ? (void *)&relay : user;
+        if (cfg->backend == PT_BACKEND_WAVEFRONT)
+            rc = render_wavefront(c, cfg, Fp, st, cancel, part_cb, part_user, &ps);
         else
-            HIP_TRY(hipMemsetAsync(d_out_rgb, 0, (size_t)F.npix * 3 * sizeof(float), st));
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(st));
-        if (cb && rc == PT_OK) cb(user, 1.0f);
+            rc = render_mega(c, cfg, Fp, st, cancel, part_cb, part_user, &ps);
+        if (rc == PT_OK || rc == PT_CANCELLED) {
+            // A cancelled part resolves what was accumulated by the samples per pixel that were accumulated
+            // (live_spp_issued, also reported through stats->samples): every pixel at full brightness over fewer
+            // samples - the same picture pt_ctx_snapshot gives.  (The reference's partial image has finished pixels at
+            // full spp and the rest black; a GPU pass covers every pixel, so "fewer samples everywhere" is its
+            // counterpart.)  Nothing accumulated yet: all zero, as the reference's untouched `pixels` vector.
+            const uint32_t spp_done = rc == PT_OK ? cfg->spp : c->live_spp_issued;
+            if (spp_done != 0u)
+                launch_resolve(st, c->acc.p, out_p, Fp.npix, spp_done, c->live_streams, c->live_m);
+            else
+                HIP_TRY(hipMemsetAsync(out_p, 0, (size_t)Fp.npix * 3 * sizeof(float), st));
+            if (rc == PT_CANCELLED && Fp.k_begin + Fp.npix < total)  // the parts that were never started
+                HIP_TRY(hipMemsetAsync(out_p + (size_t)Fp.npix * 3, 0, (size_t)(total - Fp.k_begin - Fp.npix) * 3 * sizeof(float), st));
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+        if (stats) {
+            stats->ray_bounces += ps.ray_bounces;
+            stats->samples += ps.samples;
+            stats->intersect_rays += ps.intersect_rays;
+            stats->intersect_launches += ps.intersect_launches;
+            stats->passes += ps.passes;
+            stats->ms_device += ps.ms_device;
+            stats->ms_intersect += ps.ms_intersect;
+        }
     }
+    if (cb && rc == PT_OK) cb(user, 1.0f);
     if (stats) stats->ms_total = now_ms() - t0;
     c->scene.n_bvh_nodes = c->n_bvh_nodes;
     c->scene.planar = 1u;
     c->scene.cand_scan = (c->tune.cand_scan && c->cand_ok) ? 1u : 0u;
     c->live_npix = 0;
+    c->live_out = nullptr;
     return rc;
 }
 
@@ -1041,11 +1093,19 @@ int pt_ctx_snapshot(pt_ctx *c, void *d_out_rgb, uint32_t *spp_done) {
         return PT_ERR_INVALID;
     }
     HIP_TRY(hipSetDevice(c->device));
-    // stream order: the resolve runs after every pass issued so far, i.e. over live_spp_issued samples per pixel
-    launch_resolve(c->live_stream, c->acc.p, (float *)d_out_rgb, c->live_npix, c->live_spp_issued, c->live_streams,
-                   c->live_m);
+    // stream order: the resolve runs after every pass issued so far, i.e. over live_spp_issued samples per pixel.  A call
+    // rendered in parts: the finished parts are copied from the call's own output, the part in progress is resolved,
+    // the parts not started are black.
+    float *snap = (float *)d_out_rgb;
+    hipStream_t st = c->live_stream;
+    if (c->live_k0 != 0u && c->live_out && c->live_out != snap)
+        HIP_TRY(hipMemcpyAsync(snap, c->live_out, (size_t)c->live_k0 * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    launch_resolve(st, c->acc.p, snap + (size_t)c->live_k0 * 3, c->live_npix, c->live_spp_issued, c->live_streams, c->live_m);
+    const uint32_t done = c->live_k0 + c->live_npix;
+    if (done < c->live_total)
+        HIP_TRY(hipMemsetAsync(snap + (size_t)done * 3, 0, (size_t)(c->live_total - done) * 3 * sizeof(float), st));
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(c->live_stream));
+    HIP_TRY(hipStreamSynchronize(st));
     if (spp_done) *spp_done = c->live_spp_issued;
     return PT_OK;
 }

@@ -61,9 +61,10 @@ struct alignas(16) ObjPairRec {
 // Two consecutive triangles of one mesh (world space), component by component, read with a wave-uniform
 // index.  Each component pair sits in two adjacent dwords, so after the scalar load it is an aligned SGPR
 // pair and can be the scalar operand of a packed VALU instruction (v_pk_mul_f32 / v_pk_add_f32): one ray is
-// tested against both triangles with one instruction per arithmetic step.  On gfx950 a VALU instruction
-// occupies its SIMD for 4 cycles whether it is packed or not (measured: profiles/README.md), so packing
-// halves the issue slots of the Moller-Trumbore arithmetic; every half is still an IEEE mul/add/sub.
+// tested against both triangles with one instruction per arithmetic step.  On gfx950 a packed f32 instruction
+// occupies its SIMD for 4 cycles, a scalar one for 2 with VGPR sources but for 4 with an SGPR source (measured:
+// profiles/r02_valu_issue_costs.json) - and the scene operands ARE SGPRs here, so the packed form does two
+// triangles in the 4 cycles one would take; every half is still an IEEE mul/add/sub.
 // A mesh with an odd triangle count gets an all-zero second triangle: its determinant is 0, which the
 // reference's first test rejects (mod.rs:571).
 struct alignas(16) TriPairRec {
@@ -196,11 +197,14 @@ struct FrameParams {
     uint32_t debug;                // ablation switches for profiling builds (PT_DEBUG env): 0 in production
     uint32_t chunk_pixels, chunk_first, chunk_step;  // interleaved partition (chunk_step <= 1: contiguous band)
     uint32_t n_streams;            // wavefront: K ray streams; stream b owns the call's pixels b, b+K, b+2K, ...
+    uint32_t k_begin;              // first call-local pixel of this launch's part of the call (large calls are rendered in
+                                   // parts of about a million pixels: pt_ctx_render); npix counts the part's pixels
 };
 
 // framebuffer index of the k-th pixel of this call (identity + idx_begin for a contiguous band)
 template <class Params>
 PT_HD uint32_t global_pixel(const Params &F, uint32_t k) {
+    k += F.k_begin;
     if (F.chunk_step <= 1u) return F.idx_begin + k;
     const uint32_t c = k / F.chunk_pixels, w = k - c * F.chunk_pixels;
     return F.idx_begin + (F.chunk_first + c * F.chunk_step) * F.chunk_pixels + w;
@@ -214,6 +218,7 @@ struct ShadeParams {
     uint32_t s0;  // first sample index of the pass
     uint32_t chunk_pixels, chunk_first, chunk_step;
     uint32_t n_streams;
+    uint32_t k_begin;
 };
 
 // Pixels of a call are dealt to the K streams round-robin: stream b owns the call-local pixels b, b+K, b+2K, ...

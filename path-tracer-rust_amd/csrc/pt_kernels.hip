@@ -335,6 +335,7 @@ __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, R
     P.chunk_pixels = F.chunk_pixels;
     P.chunk_first = F.chunk_first;
     P.chunk_step = F.chunk_step;
+    P.k_begin = F.k_begin;
     bool overflow = false;
     unsigned long long total = 0ull;
     uint32_t n = mb * s_here;  // rays of the current level
@@ -533,6 +534,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
     P.chunk_pixels = F.chunk_pixels;
     P.chunk_first = F.chunk_first;
     P.chunk_step = F.chunk_step;
+    P.k_begin = F.k_begin;
     bool overflow = false;
     unsigned long long total = 0ull;
     uint32_t n = mb * s_here;  // rays of the current level
@@ -766,6 +768,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_pass_bvh(DevScene S, FrameParams 
     P.chunk_pixels = F.chunk_pixels;
     P.chunk_first = F.chunk_first;
     P.chunk_step = F.chunk_step;
+    P.k_begin = F.k_begin;
     bool overflow = false;
     unsigned long long total = 0ull;
     uint32_t n = mb * s_here;  // rays of the current level
@@ -1213,6 +1216,7 @@ void launch_shade(hipStream_t st, uint32_t K, const DevScene &S, const FramePara
     P.chunk_pixels = F.chunk_pixels;
     P.chunk_first = F.chunk_first;
     P.chunk_step = F.chunk_step;
+    P.k_begin = F.k_begin;
     hipLaunchKernelGGL(k_shade, dim3(K), dim3(kBlock), lds, st, S, P, qin, qout, hit, cnt_in, cnt_out, cap, acc,
                        flags, m);
 }
