@@ -242,8 +242,10 @@ int pt_render_multi(const pt_config *cfg, uint32_t n_ranks, const pt_camera *cam
 
 /* Progressive preview (RenderUpdate, mod.rs:881-885, sent every 500 ms by mod.rs:965-982): callable from the
  * progress callback of pt_ctx_render on the same thread.  Resolves what has been accumulated so far into
- * d_out_rgb (band layout) and reports how many samples per pixel it holds.  The reference's snapshot is a
- * random subset of finished pixels; this one is every pixel at partial spp. */
+ * d_out_rgb (the call's layout, pt_config_pixels(cfg)*3 floats) and reports how many samples per pixel it holds.  The
+ * reference's snapshot is a random subset of finished pixels; this one is every pixel at partial spp.  (A wavefront call
+ * of more than 1.5 M pixels is rendered in parts of 2^20 pixels: the snapshot then shows the finished parts final, the
+ * part in progress at partial spp - spp_done speaks of that part - and the parts not started black.) */
 int pt_ctx_snapshot(pt_ctx *ctx, void *d_out_rgb, uint32_t *spp_done);
 
 /* ---- the one collective of the path: the framebuffer gather over RCCL (xGMI) ---------------------------------

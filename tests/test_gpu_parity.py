@@ -1100,3 +1100,66 @@ def test_comm_gather_world_1_in_a_clean_process():
     r = subprocess.run([sys.executable, os.path.join(ptlib.ROOT, "tools", "comm_probe.py")], capture_output=True, text=True,
                        timeout=300)
     assert r.returncode == 0 and "gather ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_large_call_in_parts_cancel_and_snapshot(gpu):
+    """A call of more than 1.5 M pixels is rendered as parts of 2^20 call-local pixels (pt_ctx_render).  Same bits as the
+    megakernel (one part); a cancel raised while the second part is in progress leaves part one final, part two
+    averaged over its accumulated samples and nothing else; a snapshot taken at that moment shows exactly that."""
+    L, ctx = gpu
+    sc = ptlib.load_scene_py(ptlib.scene_path("cornell"))
+    set_scene(gpu, sc)
+    w, h, spp = 2048, 1040, 3  # 2 129 920 pixels: parts of 1 048 576 + 1 048 576 + 32 768
+    npix, part = w * h, 1 << 20
+    nbytes = npix * 12
+    d_out, d_snap = C.c_void_p(), C.c_void_p()
+    assert L.pt_device_malloc(0, nbytes, C.byref(d_out)) == 0 and L.pt_device_malloc(0, nbytes, C.byref(d_snap)) == 0
+
+    def download(ptr):
+        host = np.zeros((npix, 3), dtype=np.float32)
+        assert L.pt_device_download(0, host.ctypes.data_as(C.c_void_p), ptr, nbytes) == 0
+        return host
+
+    st = PtStats()
+    cfg = PtConfig(w, h, spp, ptlib.BACKEND_MEGAKERNEL, 4, 0, 0, 0, 0)
+    assert L.pt_ctx_render(ctx, C.byref(cfg), d_out, None, None, None, None, C.byref(st)) == 0, L.pt_last_error()
+    whole_mega, bounces = download(d_out), st.ray_bounces
+    cfg = PtConfig(w, h, spp, ptlib.BACKEND_WAVEFRONT, 4, 0, 0, 0, 0)
+    assert L.pt_ctx_render(ctx, C.byref(cfg), d_out, None, None, None, None, C.byref(st)) == 0, L.pt_last_error()
+    assert np.array_equal(download(d_out), whole_mega) and st.ray_bounces == bounces
+    # one sample per pass; cancel from the callback once the second part is under way
+    flag = (C.c_uint8 * 1)(0)
+    snaps = []
+
+    def on_progress(user, frac):
+        if frac > 0.5 and not flag[0]:
+            n = C.c_uint32()
+            assert L.pt_ctx_snapshot(ctx, d_snap, C.byref(n)) == 0, L.pt_last_error()
+            snaps.append((n.value, download(d_snap)))
+            flag[0] = 1
+
+    cb = ptlib.PROGRESS_FN(on_progress)
+    spp2 = 8
+    cfg = PtConfig(w, h, spp2, ptlib.BACKEND_WAVEFRONT, 4, 0, 0, part, 0)
+    cfg.progress_ms = ptlib.PROGRESS_EVERY_PASS
+    rc = L.pt_ctx_render(ctx, C.byref(cfg), d_out, None, C.cast(flag, C.c_void_p), C.cast(cb, C.c_void_p), None, C.byref(st))
+    assert rc == ptlib.PT_CANCELLED and len(snaps) == 1
+    got = download(d_out)
+    done2 = (st.samples - part * spp2) // part  # samples per pixel the second part got
+    assert st.samples == part * spp2 + part * done2 and 1 <= done2 < spp2
+    full = PtConfig(w, h, spp2, ptlib.BACKEND_WAVEFRONT, 4, 0, part, 0, 0)  # part one as a band of its own
+    band = np.zeros((npix, 3), np.float32)
+    assert L.pt_render(C.byref(full), C.byref(sc.cam), sc.objs, sc.n_objs, sc.tris, sc.n_tris, _np_f(band), None, None, None,
+                       C.byref(st)) == 0
+    assert np.array_equal(got[:part], band[:part])
+    half = PtConfig(w, h, done2, ptlib.BACKEND_WAVEFRONT, 4, part, 2 * part, 0, 0)
+    assert L.pt_render(C.byref(half), C.byref(sc.cam), sc.objs, sc.n_objs, sc.tris, sc.n_tris, _np_f(band), None, None, None,
+                       C.byref(st)) == 0
+    assert np.array_equal(got[part:2 * part], band[part:2 * part])
+    assert not got[2 * part:].any()
+    # the snapshot: part one final, part two over the samples it had then, the rest black
+    n_snap, snap = snaps[0]
+    assert np.array_equal(snap[:part], got[:part]) and not snap[2 * part:].any() and 1 <= n_snap <= done2
+    if n_snap == done2:
+        assert np.array_equal(snap[part:2 * part], got[part:2 * part])
+    assert L.pt_device_free(0, d_out) == 0 and L.pt_device_free(0, d_snap) == 0
