@@ -730,7 +730,7 @@ __host__ __device__ inline size_t pass_bvh_lds_bytes(const DevScene &S, uint32_t
     return pass_bvh_leaf_offset(S, m) + (size_t)(kBlock / 64u) * (64u * 8u + kLeafListCap * 4u);
 }
 
-__global__ __launch_bounds__(kBlock, 5) void k_pass_bvh(DevScene S, FrameParams F, RayQueue q0, RayQueue q1, uint32_t cap,
+__global__ __launch_bounds__(kBlock, 4) void k_pass_bvh(DevScene S, FrameParams F, RayQueue q0, RayQueue q1, uint32_t cap,
                                                         uint32_t s0, uint32_t s_here, uint32_t m,
                                                         unsigned long long *__restrict__ acc,
                                                         unsigned long long *__restrict__ blk_rays,
