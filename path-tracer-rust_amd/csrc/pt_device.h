@@ -88,6 +88,15 @@ constexpr int32_t kNoBvh = 0x7fffffff;
 constexpr uint32_t kNoTri = 0x7fffffffu;
 constexpr uint32_t kBvhStack = 24;          // per-lane traversal stack entries (LDS; u16 each when nodes are staged)
 constexpr uint32_t kBvhMinTris = 16;        // meshes with fewer triangles are scanned linearly
+// A BVH leaf is a run of up to kBvhLeafPairs consecutive pair records.  A leaf reference is ~(first record << 2 | count - 1).
+// Dense leaf batches make a pair test cheaper than a node step (k_pass_bvh: about 1.7 against 2.3 wave-instructions per
+// lane-unit of work), so the last two levels of the tree are better spent as tests: mesh.json 14.6 -> see DESIGN.
+#ifndef PT_BVH_LEAF_PAIRS
+#define PT_BVH_LEAF_PAIRS 4
+#endif
+constexpr uint32_t kBvhLeafPairs = PT_BVH_LEAF_PAIRS;
+PT_HD uint32_t leaf_first(uint32_t code) { return code >> 2; }
+PT_HD uint32_t leaf_count(uint32_t code) { return (code & 3u) + 1u; }
 constexpr uint32_t kBvhMaxLdsNodes = 512;   // 32 KiB of nodes at most are staged in LDS (+ 24 KiB of stacks < 64 KiB)
 
 // ---- candidate scan (k_pass): see intersect_cand -----------------------------------------------------------------
@@ -457,10 +466,10 @@ struct Stack16 {
     typedef uint16_t T;
     uint32_t pair_base;
     __device__ __forceinline__ T enc(int32_t r) const {
-        return (T)(r >= 0 ? (uint32_t)r : (0x8000u | ((uint32_t)(~r) - pair_base)));
+        return (T)(r >= 0 ? (uint32_t)r : (0x8000u | ((uint32_t)(~r) - (pair_base << 2))));
     }
     __device__ __forceinline__ int32_t dec(T e) const {
-        return (e & 0x8000u) ? ~(int32_t)((uint32_t)(e & 0x7fffu) + pair_base) : (int32_t)e;
+        return (e & 0x8000u) ? ~(int32_t)((uint32_t)(e & 0x7fffu) + (pair_base << 2)) : (int32_t)e;
     }
 };
 struct Stack32 {
@@ -523,7 +532,9 @@ __device__ __forceinline__ void bvh_closest(const DevScene &S, NodePtr nodes, Co
         if (__builtin_amdgcn_ballot_w64(cur != kDone) == 0ull) break;  // every lane of the wave is done
         // 2. leaf: two triangles (lanes still descending - early exit by quorum - and finished lanes sit out)
         if (cur < 0 && cur != kDone) {
-            test_pair<false>(S.tri_pairs[~cur], ox2, oy2, oz2, dx2, dy2, dz2, mt, mid);
+            const uint32_t code = (uint32_t)~cur;
+            for (uint32_t j = 0; j < leaf_count(code); ++j)
+                test_pair<false>(S.tri_pairs[leaf_first(code) + j], ox2, oy2, oz2, dx2, dy2, dz2, mt, mid);
             if (sp == 0u) {
                 cur = kDone;
             } else {
@@ -553,7 +564,7 @@ struct LeafLds {
     unsigned long long *keys;  // [64] of this wave
     uint32_t *list;            // [kLeafListCap] of this wave: lane | leaf pair record << 6
 };
-constexpr uint32_t kLeafListCap = 192;  // < 64 left over + 64 appended by one step
+constexpr uint32_t kLeafListCap = 64u + 64u * kBvhLeafPairs;  // < 64 left over + 64 leaves of kBvhLeafPairs records appended by one step
 
 template <class NodePtr, class Codec>
 __device__ __forceinline__ void bvh_closest_postponed(const DevScene &S, NodePtr nodes, Codec codec, typename Codec::T *stack,
@@ -629,9 +640,15 @@ __device__ __forceinline__ void bvh_closest_postponed(const DevScene &S, NodePtr
         }
         const uint64_t ml = __builtin_amdgcn_ballot_w64(at_leaf);
         if (ml != 0ull) {
-            if (at_leaf)
-                L.list[n_leaf + __builtin_amdgcn_mbcnt_hi((uint32_t)(ml >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ml, 0u))] = lane | (leaf << 6);
-            n_leaf += (uint32_t)__builtin_popcountll(ml);
+            for (uint32_t j = 0; j < kBvhLeafPairs; ++j) {  // record j of every leaf that has one
+                const bool has = at_leaf && j < leaf_count(leaf);
+                const uint64_t mj = j == 0u ? ml : __builtin_amdgcn_ballot_w64(has);
+                if (mj == 0ull) break;
+                if (has)
+                    L.list[n_leaf + __builtin_amdgcn_mbcnt_hi((uint32_t)(mj >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mj, 0u))] =
+                        lane | ((leaf_first(leaf) + j) << 6);
+                n_leaf += (uint32_t)__builtin_popcountll(mj);
+            }
             while (n_leaf >= n_act) {
                 n_leaf -= n_act;
                 leaf_batch(n_leaf, n_act);

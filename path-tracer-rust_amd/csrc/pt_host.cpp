@@ -115,20 +115,24 @@ struct BvhBuilder {
         lo = mk(inf, inf, inf);
         hi = mk(-inf, -inf, -inf);
         depth_max = depth > depth_max ? depth : depth_max;
-        if (e - b <= 2) {  // leaf = one TriPairRec
-            TriPairRec rec{};
-            rec.id[0] = rec.id[1] = kNoTri;  // a filler half is all zeros: determinant 0, rejected (mod.rs:571)
-            for (size_t k = b; k < e; ++k) {
-                const uint32_t hf = (uint32_t)(k - b);
-                const BuildTri &q = t[k];
-                rec.ax[hf] = q.a.x, rec.ay[hf] = q.a.y, rec.az[hf] = q.a.z;
-                rec.e1x[hf] = q.e1.x, rec.e1y[hf] = q.e1.y, rec.e1z[hf] = q.e1.z;
-                rec.e2x[hf] = q.e2.x, rec.e2y[hf] = q.e2.y, rec.e2z[hf] = q.e2.z;
-                rec.id[hf] = q.id;
-                grow(lo, hi, q.lo, q.hi);
+        if (e - b <= 2u * kBvhLeafPairs) {  // leaf = up to kBvhLeafPairs consecutive TriPairRecs
+            const size_t first = out.tri_pairs.size();
+            for (size_t k0 = b; k0 < e; k0 += 2) {
+                TriPairRec rec{};
+                rec.id[0] = rec.id[1] = kNoTri;  // a filler half is all zeros: determinant 0, rejected (mod.rs:571)
+                for (size_t k = k0; k < e && k < k0 + 2; ++k) {
+                    const uint32_t hf = (uint32_t)(k - k0);
+                    const BuildTri &q = t[k];
+                    rec.ax[hf] = q.a.x, rec.ay[hf] = q.a.y, rec.az[hf] = q.a.z;
+                    rec.e1x[hf] = q.e1.x, rec.e1y[hf] = q.e1.y, rec.e1z[hf] = q.e1.z;
+                    rec.e2x[hf] = q.e2.x, rec.e2y[hf] = q.e2.y, rec.e2z[hf] = q.e2.z;
+                    rec.id[hf] = q.id;
+                    grow(lo, hi, q.lo, q.hi);
+                }
+                out.tri_pairs.push_back(rec);
             }
-            out.tri_pairs.push_back(rec);
-            return ~(int32_t)(out.tri_pairs.size() - 1);
+            const size_t count = out.tri_pairs.size() - first;
+            return ~(int32_t)((first << 2) | (count - 1));
         }
         // surface-area-heuristic split: for each axis sort by centroid and sweep; only even left counts are
         // considered so that leaves are full pairs wherever possible.  Ties are broken by triangle id: the tree
