@@ -698,7 +698,7 @@ int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uin
         // bit 1: node and leaf references fit 16 bits (u16 traversal stacks); bit 0: nodes staged in LDS by every
         // workgroup.  With the walks done in dense waves (k_intersect<true>) occupancy is worth more than LDS-resident
         // nodes - mesh.json: 7.7 G bounces/s staged, 8.6 G from L1/L2 - so staging is opt-in (PT_BVH_LDS=1).
-        const bool ref16 = c->n_bvh_nodes < 0x8000u && ((uint64_t)fs.bvh_pair_span << 2) < 0x8000u;
+        const bool ref16 = c->n_bvh_nodes < 0x8000u && ((uint64_t)fs.bvh_pair_span << kBvhLeafBits) < 0x8000u;
         const bool stage = ref16 && c->n_bvh_nodes <= kBvhMaxLdsNodes && c->tune.bvh_lds;
         c->scene.bvh_in_lds = (ref16 ? 2u : 0u) | (stage ? 1u : 0u);
     }

@@ -88,15 +88,16 @@ constexpr int32_t kNoBvh = 0x7fffffff;
 constexpr uint32_t kNoTri = 0x7fffffffu;
 constexpr uint32_t kBvhStack = 24;          // per-lane traversal stack entries (LDS; u16 each when nodes are staged)
 constexpr uint32_t kBvhMinTris = 16;        // meshes with fewer triangles are scanned linearly
-// A BVH leaf is a run of up to kBvhLeafPairs consecutive pair records.  A leaf reference is ~(first record << 2 | count - 1).
+// A BVH leaf is a run of up to kBvhLeafPairs consecutive pair records.  A leaf reference is ~(first record << kBvhLeafBits | count - 1).
 // Dense leaf batches make a pair test cheaper than a node step (k_pass_bvh: about 1.7 against 2.3 wave-instructions per
 // lane-unit of work), so the last two levels of the tree are better spent as tests: mesh.json 14.6 -> see DESIGN.
 #ifndef PT_BVH_LEAF_PAIRS
 #define PT_BVH_LEAF_PAIRS 4
 #endif
 constexpr uint32_t kBvhLeafPairs = PT_BVH_LEAF_PAIRS;
-PT_HD uint32_t leaf_first(uint32_t code) { return code >> 2; }
-PT_HD uint32_t leaf_count(uint32_t code) { return (code & 3u) + 1u; }
+constexpr uint32_t kBvhLeafBits = kBvhLeafPairs <= 2 ? 1 : (kBvhLeafPairs <= 4 ? 2 : (kBvhLeafPairs <= 8 ? 3 : 4));
+PT_HD uint32_t leaf_first(uint32_t code) { return code >> kBvhLeafBits; }
+PT_HD uint32_t leaf_count(uint32_t code) { return (code & ((1u << kBvhLeafBits) - 1u)) + 1u; }
 constexpr uint32_t kBvhMaxLdsNodes = 512;   // 32 KiB of nodes at most are staged in LDS (+ 24 KiB of stacks < 64 KiB)
 
 // ---- candidate scan (k_pass): see intersect_cand -----------------------------------------------------------------
@@ -466,10 +467,10 @@ struct Stack16 {
     typedef uint16_t T;
     uint32_t pair_base;
     __device__ __forceinline__ T enc(int32_t r) const {
-        return (T)(r >= 0 ? (uint32_t)r : (0x8000u | ((uint32_t)(~r) - (pair_base << 2))));
+        return (T)(r >= 0 ? (uint32_t)r : (0x8000u | ((uint32_t)(~r) - (pair_base << kBvhLeafBits))));
     }
     __device__ __forceinline__ int32_t dec(T e) const {
-        return (e & 0x8000u) ? ~(int32_t)((uint32_t)(e & 0x7fffu) + (pair_base << 2)) : (int32_t)e;
+        return (e & 0x8000u) ? ~(int32_t)((uint32_t)(e & 0x7fffu) + (pair_base << kBvhLeafBits)) : (int32_t)e;
     }
 };
 struct Stack32 {

@@ -132,7 +132,7 @@ struct BvhBuilder {
                 out.tri_pairs.push_back(rec);
             }
             const size_t count = out.tri_pairs.size() - first;
-            return ~(int32_t)((first << 2) | (count - 1));
+            return ~(int32_t)((first << kBvhLeafBits) | (count - 1));
         }
         // surface-area-heuristic split: for each axis sort by centroid and sweep; only even left counts are
         // considered so that leaves are full pairs wherever possible.  Ties are broken by triangle id: the tree
