@@ -650,8 +650,8 @@ def test_pass_kernel_equals_separate_kernels(gpu, sid):
 def test_pass_kernel_full_size(gpu):
     """Bench geometry (1024x768, 16 K streams): k_pass against the separate kernels and against the megakernel."""
     sc = ptlib.load_scene_py(ptlib.scene_path("cornell"))
-    a, sa = _render_flags(gpu, sc, 1024, 768, 48, 5, 0)
-    b, sb = _render_flags(gpu, sc, 1024, 768, 48, 5, PT_FLAG_SEPARATE_KERNELS)
+    a, sa = _render_flags(gpu, sc, 1024, 768, 48, 5, 0, rays_per_pass=32 << 20)
+    b, sb = _render_flags(gpu, sc, 1024, 768, 48, 5, PT_FLAG_SEPARATE_KERNELS, rays_per_pass=32 << 20)
     assert sa.ray_bounces == sb.ray_bounces and sa.passes == 2
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     m, sm = gpu_render(gpu, sc, 1024, 768, 48, 5, backend=ptlib.BACKEND_MEGAKERNEL)

@@ -12,7 +12,7 @@ SRC = textwrap.dedent(r"""
     #include <vector>
     #include "pt_device.h"
     using namespace pt;
-    struct P { uint32_t idx_begin, chunk_pixels, chunk_first, chunk_step; };
+    struct P { uint32_t idx_begin, chunk_pixels, chunk_first, chunk_step, k_begin; };
     int main() {
         // 1. every pixel of a call belongs to exactly one (stream, slot); the accumulator slot k_resolve reads back is
         //    the one k_pass / k_shade wrote
