@@ -64,6 +64,8 @@ struct Tuning {
     bool pass_bvh = true;      // PT_PASS_BVH=0: BVH scenes through the separate kernels
     bool bvh_lds = false;      // PT_BVH_LDS=1: stage BVH nodes in LDS (separate kernels only)
     bool cand_scan = true;     // PT_CAND_SCAN=0: k_pass scans every triangle per ray (the round-1 form) instead of candidates
+    bool cand_bvh = true;      // PT_CAND_BVH=0: scenes with BVH meshes run k_pass_bvh (scan + parked walks) instead of
+                               // the candidate scan with parked walks (k_pass_cand<.., BVH>)
     uint32_t leaf_quorum = 12; // PT_LEAF_QUORUM: lanes on a leaf that send a walking wave to the triangle code
     uint64_t streams = 0;      // PT_STREAMS: ray streams per pass (0 = derived from the frame)
     uint32_t debug = 0;
@@ -78,6 +80,7 @@ static Tuning read_tuning() {
     t.pass_bvh = num("PT_PASS_BVH", 1) != 0;
     t.bvh_lds = num("PT_BVH_LDS", 0) != 0;
     t.cand_scan = num("PT_CAND_SCAN", 1) != 0;
+    t.cand_bvh = num("PT_CAND_BVH", 1) != 0;
     t.leaf_quorum = (uint32_t)num("PT_LEAF_QUORUM", 12);
     const long long st = num("PT_STREAMS", 0);
     t.streams = st > 0 ? (uint64_t)st : 0;
@@ -105,6 +108,7 @@ struct pt_ctx {
     DevBuf<FlatPairRec> d_flat;
     DevBuf<CandPairRec> d_cand;
     DevBuf<uint32_t> d_rank_id;
+    DevBuf<uint32_t> d_tri_rank;
     DevBuf<SurfRec> d_surf;
     bool cand_ok = false;
     uint32_t n_bvh_nodes = 0;
@@ -244,6 +248,14 @@ hipEvent_t get_event(pt_ctx *c, size_t i) {
     return c->ev_pool[i];
 }
 
+// does a frame with these flags run the candidate scan (k_pass_cand)?  Scenes with BVH meshes: with parked walks, unless
+// their nodes are staged in LDS (PT_BVH_LDS=1) or PT_CAND_BVH=0 asks for k_pass_bvh.
+static uint32_t cand_scan_for(const pt_ctx *c, uint32_t flags) {
+    if (!c->tune.cand_scan || !c->cand_ok || (flags & PT_FLAG_NO_BVH)) return 0u;
+    if (c->n_bvh_nodes != 0u && (!c->tune.cand_bvh || (c->scene.bvh_in_lds & 1u))) return 0u;
+    return 1u;
+}
+
 double now_ms() {
     using namespace std::chrono;
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
@@ -358,7 +370,7 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
                 }
                 HIP_TRY(hipEventRecord(a, st));
             }
-            if (c->scene.n_bvh_nodes != 0u)
+            if (c->scene.n_bvh_nodes != 0u && !c->scene.cand_scan)
                 launch_pass_bvh(st, K, c->scene, F, queue_of(c, 0), queue_of(c, 1), cap, s0, s_here, m, c->acc.p,
                                 c->blk_rays.p, c->flags.p);
             else
@@ -609,6 +621,7 @@ void pt_ctx_destroy(pt_ctx *c) {
     c->d_flat.release();
     c->d_cand.release();
     c->d_rank_id.release();
+    c->d_tri_rank.release();
     c->d_surf.release();
     c->d_boxes.release();
     c->q_o.release();
@@ -651,7 +664,8 @@ int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uin
         (rc = c->d_mats.ensure(fs.mats.size())) || (rc = c->d_tshade.ensure(fs.tri_shade.size())) ||
         (rc = c->d_nodes.ensure(fs.bvh_nodes.size())) || (rc = c->d_sph.ensure(fs.sph_pairs.size())) ||
         (rc = c->d_flat.ensure(fs.flat_pairs.size())) || (rc = c->d_cand.ensure(fs.cand_pairs.size())) ||
-        (rc = c->d_rank_id.ensure(fs.rank_id.size())) || (rc = c->d_surf.ensure(fs.surf.size())))
+        (rc = c->d_rank_id.ensure(fs.rank_id.size())) || (rc = c->d_surf.ensure(fs.surf.size())) ||
+        (rc = c->d_tri_rank.ensure(fs.tri_rank.size())))
         return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (!fs.objs.empty())
@@ -681,7 +695,9 @@ int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uin
     c->scene.flat_pairs = c->d_flat.p;
     c->scene.cand_pairs = c->d_cand.p;
     HIP_TRY(hipMemcpy(c->d_surf.p, fs.surf.data(), fs.surf.size() * sizeof(SurfRec), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_tri_rank.p, fs.tri_rank.data(), fs.tri_rank.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     c->scene.rank_id = c->d_rank_id.p;
+    c->scene.tri_rank = c->d_tri_rank.p;
     c->scene.surf = c->d_surf.p;
     c->scene.n_sph_pairs = (uint32_t)fs.sph_pairs.size();
     c->scene.n_flat_pairs = (uint32_t)fs.flat_pairs.size();
@@ -689,7 +705,13 @@ int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uin
     c->scene.n_other_pairs = fs.n_other_pairs;
     c->cand_ok = fs.cand_ok;
     c->scene.cand_staged = 0u;
-    c->scene.cand_scan = (c->tune.cand_scan && c->cand_ok) ? 1u : 0u;
+    c->scene.surf_staged = 0u;
+#ifdef PT_WALK_STATS
+    if (!c->scene.stats) {
+        HIP_TRY(hipMalloc((void **)&c->scene.stats, 16 * sizeof(unsigned long long)));  // instrumented builds only: never freed
+        HIP_TRY(hipMemset(c->scene.stats, 0, 16 * sizeof(unsigned long long)));
+    }
+#endif
     c->n_bvh_nodes = (uint32_t)fs.bvh_nodes.size();
     c->scene.bvh_nodes = c->d_nodes.p;
     c->scene.n_bvh_nodes = c->n_bvh_nodes;
@@ -702,7 +724,9 @@ int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uin
         const bool stage = ref16 && c->n_bvh_nodes <= kBvhMaxLdsNodes && c->tune.bvh_lds;
         c->scene.bvh_in_lds = (ref16 ? 2u : 0u) | (stage ? 1u : 0u);
     }
+    c->scene.cand_scan = cand_scan_for(c, 0u);
     c->scene.bvh_pair_base = fs.bvh_pair_base;
+    c->scene.bvh_stack = fs.bvh_stack;
     c->scene.leaf_quorum = c->tune.leaf_quorum;  // mesh.json: 65 (all) 11.7, 32 12.5, 16 12.8, 8 12.8, 1 11.0 G bounces/s
     c->scene.objs = c->d_objs.p;
     c->scene.obj_pairs = c->d_opairs.p;
@@ -761,8 +785,8 @@ const char *pt_ctx_pass_kernel(const pt_ctx *c, uint32_t flags) {
     const bool bvh_ok = n_nodes == 0u || (!(c->scene.bvh_in_lds & 1u) && c->tune.pass_bvh);
     const bool one_kernel = bvh_ok && c->tune.pass_kernel && !(flags & PT_FLAG_SEPARATE_KERNELS);
     if (!one_kernel) return "k_intersect";
-    if (n_nodes != 0u) return "k_pass_bvh";
-    return (c->tune.cand_scan && c->cand_ok && !no_bvh) ? "k_pass_cand" : "k_pass";
+    if (cand_scan_for(c, flags)) return "k_pass_cand";
+    return n_nodes != 0u ? "k_pass_bvh" : "k_pass";
 }
 
 int pt_ctx_set_profiling(pt_ctx *c, int enabled) {
@@ -888,7 +912,7 @@ int pt_ctx_render(pt_ctx *c, const pt_config *cfg, void *d_out_rgb, void *hip_st
     // PT_FLAG_NO_BVH: scan meshes triangle by triangle as the reference does (same result, for A/B checks)
     c->scene.n_bvh_nodes = (cfg->flags & PT_FLAG_NO_BVH) ? 0u : c->n_bvh_nodes;
     c->scene.planar = (cfg->flags & PT_FLAG_NO_BVH) ? 0u : 1u;
-    c->scene.cand_scan = (c->tune.cand_scan && c->cand_ok && !(cfg->flags & PT_FLAG_NO_BVH)) ? 1u : 0u;
+    c->scene.cand_scan = cand_scan_for(c, cfg->flags);
     const double t0 = now_ms();
     // Parts.  The wavefront kernels are tuned for streams of a few dozen pixels with a couple of thousand rays per pass
     // (accumulators, ray slots and deferral buffers share 40 KB of LDS per workgroup); a call of many millions of pixels
@@ -961,7 +985,7 @@ int pt_ctx_render(pt_ctx *c, const pt_config *cfg, void *d_out_rgb, void *hip_st
     if (stats) stats->ms_total = now_ms() - t0;
     c->scene.n_bvh_nodes = c->n_bvh_nodes;
     c->scene.planar = 1u;
-    c->scene.cand_scan = (c->tune.cand_scan && c->cand_ok) ? 1u : 0u;
+    c->scene.cand_scan = cand_scan_for(c, 0u);
     c->live_npix = 0;
     c->live_out = nullptr;
     return rc;
@@ -1272,5 +1296,16 @@ int pt_render_multi(const pt_config *cfg, uint32_t n_ranks, const pt_camera *cam
         }
     return PT_OK;
 }
+
+#ifdef PT_WALK_STATS
+// instrumented builds only (tools/walk_stats.py): read and clear the walk counters
+int pt_debug_walk_stats(pt_ctx *c, unsigned long long *out16) {
+    if (!c || !c->scene.stats) return PT_ERR_INVALID;
+    hipDeviceSynchronize();
+    hipMemcpy(out16, c->scene.stats, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    hipMemset(c->scene.stats, 0, 16 * sizeof(unsigned long long));
+    return PT_OK;
+}
+#endif
 
 }  // extern "C"

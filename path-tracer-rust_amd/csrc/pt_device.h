@@ -176,6 +176,7 @@ struct DevScene {
     uint32_t n_bvh_nodes;  // 0: no mesh of the scene has a BVH (or BVH use is switched off for this frame)
     uint32_t bvh_in_lds;   // bit 0: nodes are staged in LDS; bit 1: child references fit 16 bits (u16 traversal stacks)
     uint32_t bvh_pair_base;  // first TriPairRec that is a BVH leaf (leaf references on a u16 stack are relative to it)
+    uint32_t bvh_stack;      // traversal-stack entries the deepest tree of the scene needs (<= kBvhStack): k_pass_cand sizes its LDS by it
     uint32_t leaf_quorum;    // BVH walk: lanes on a leaf that send the wave to the triangle code (see bvh_closest)
     uint32_t planar;         // 0: every triangle through the general test_pair (PT_FLAG_NO_BVH)
     // candidate scan (scenes without BVH meshes): spheres, filters of the flat pair records, the other pair records
@@ -188,11 +189,27 @@ struct DevScene {
     const CandPairRec *cand_pairs;  // the pair records of every mesh without a BVH
     const uint32_t *rank_id;        // [n_objs + n_tris]
     const SurfRec *surf;            // [n_objs + n_tris], by rank
+    const uint32_t *tri_rank;       // [n_tris]: rank of a triangle (BVH walks report triangle indices)
     uint32_t n_sph_pairs, n_flat_pairs, n_cand_pairs;
     uint32_t n_other_pairs;         // cand_pairs [0, n_other_pairs) have no filter: candidates for every ray
     uint32_t cand_scan;             // 1: k_pass uses the candidate scan
     uint32_t cand_staged;           // 1: the workgroup holds cand_pairs in LDS
+    uint32_t surf_staged;           // 1: ... and surf (set per launch: launch_pass)
+#ifdef PT_WALK_STATS
+    unsigned long long *stats;      // [16] counters of a -DPT_WALK_STATS build (tools/walk_stats.py): never in the shipped library
+#endif
 };
+#ifdef PT_WALK_STATS
+// v is wave-uniform; one lane of the active ones adds it
+#define PT_WSTAT(S, i, v)                                                                               \
+    do {                                                                                                \
+        const unsigned long long v_ = (unsigned long long)(v);                                          \
+        const uint64_t m_ = __builtin_amdgcn_ballot_w64(true);                                          \
+        if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m_)) atomicAdd((S).stats + (i), v_);       \
+    } while (0)
+#else
+#define PT_WSTAT(S, i, v) do { } while (0)
+#endif
 
 // per-frame constants
 struct FrameParams {
@@ -563,9 +580,9 @@ __device__ __forceinline__ unsigned long long load_key(const unsigned long long 
 
 struct LeafLds {
     unsigned long long *keys;  // [64] of this wave
-    uint32_t *list;            // [kLeafListCap] of this wave: lane | leaf pair record << 6
+    uint32_t *list;            // [kLeafListCap] of this wave: lane | leaf code << 6 (leaf_first / leaf_count)
 };
-constexpr uint32_t kLeafListCap = 64u + 64u * kBvhLeafPairs;  // < 64 left over + 64 leaves of kBvhLeafPairs records appended by one step
+constexpr uint32_t kLeafListCap = 128u;  // < 64 left over + at most 64 leaves appended by one step
 
 template <class NodePtr, class Codec>
 __device__ __forceinline__ void bvh_closest_postponed(const DevScene &S, NodePtr nodes, Codec codec, typename Codec::T *stack,
@@ -596,69 +613,85 @@ __device__ __forceinline__ void bvh_closest_postponed(const DevScene &S, NodePtr
         rd.x = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(d.x)));
         rd.y = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(d.y)));
         rd.z = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(d.z)));
-        if (valid) {
-            const TriPairRec tr = S.tri_pairs[ent >> 6];
-            unsigned long long k2[2];
-            float th[2];
-            pair_test_keys(tr, ro, rd, k2, th);
-            atomicMin(&L.keys[ent & 63u], k2[0]);
-            atomicMin(&L.keys[ent & 63u], k2[1]);
+        // an entry is a whole leaf: its records one after the other (nearly every leaf of a built tree is full)
+        const uint32_t code = ent >> 6;
+        const uint32_t first = leaf_first(code), cnt = valid ? leaf_count(code) : 0u;
+        for (uint32_t r = 0; r < kBvhLeafPairs; ++r) {
+            const bool has = r < cnt;
+            if (r != 0u && __builtin_amdgcn_ballot_w64(has) == 0ull) break;
+            if (has) {
+                const TriPairRec tr = S.tri_pairs[first + r];
+                unsigned long long k2[2];
+                float th[2];
+                pair_test_keys(tr, ro, rd, k2, th);
+                atomicMin(&L.keys[ent & 63u], k2[0]);
+                atomicMin(&L.keys[ent & 63u], k2[1]);
+            }
         }
     };
     uint32_t sp = 0;
+    typename Codec::T *top = stack;  // &stack[sp * stride]: this lane's column of the workgroup's stacks
     int32_t cur = root;
+    PT_WSTAT(S, 0, n_act);  // walks
+    PT_WSTAT(S, 10, 1);     // wave-walks
     for (;;) {  // wave-uniform loop: every lane that still has work takes one step per trip
         if (__builtin_amdgcn_ballot_w64(cur != kDone) == 0ull) break;
-        bool at_leaf = false;
+        PT_WSTAT(S, 1, 1);                                                                              // trips
+        PT_WSTAT(S, 2, __builtin_popcountll(__builtin_amdgcn_ballot_w64(cur != kDone)));                // lanes with work
+        PT_WSTAT(S, 3, __builtin_popcountll(__builtin_amdgcn_ballot_w64(cur >= 0)));                    // node steps
+        bool at_leaf = false, pop = false;
         uint32_t leaf = 0;
         if (cur >= 0) {
             const BvhNode n = nodes[cur];
             bool h0, h1;
             f32x2 tin;
             hit_boxes(n, ivx, ivy, ivz, oix, oiy, oiz, bound, &h0, &h1, &tin);
+            const bool first0 = tin[0] <= tin[1];
             if (h0 && h1) {
-                const bool first0 = tin[0] <= tin[1];
-                if (sp < kBvhStack) stack[sp * stride] = codec.enc(first0 ? n.c[1] : n.c[0]);
-                ++sp;  // (the host guarantees tree depth < kBvhStack)
+                if (sp < S.bvh_stack) *top = codec.enc(first0 ? n.c[1] : n.c[0]);
+                ++sp;  // (the host guarantees tree depth < DevScene.bvh_stack <= kBvhStack)
+                top += stride;
                 cur = first0 ? n.c[0] : n.c[1];
             } else if (h0 || h1) {
                 cur = h0 ? n.c[0] : n.c[1];
-            } else if (sp != 0u) {
-                --sp;
-                cur = codec.dec(stack[sp * stride]);
             } else {
-                cur = kDone;
+                pop = true;
             }
         } else if (cur != kDone) {
             at_leaf = true;
             leaf = (uint32_t)~cur;
+            pop = true;
+        }
+        if (pop) {  // one place for both: nothing below this node / the leaf is on the list
             if (sp == 0u) {
                 cur = kDone;
             } else {
                 --sp;
-                cur = codec.dec(stack[sp * stride]);
+                top -= stride;
+                cur = codec.dec(*top);
             }
         }
         const uint64_t ml = __builtin_amdgcn_ballot_w64(at_leaf);
         if (ml != 0ull) {
-            for (uint32_t j = 0; j < kBvhLeafPairs; ++j) {  // record j of every leaf that has one
-                const bool has = at_leaf && j < leaf_count(leaf);
-                const uint64_t mj = j == 0u ? ml : __builtin_amdgcn_ballot_w64(has);
-                if (mj == 0ull) break;
-                if (has)
-                    L.list[n_leaf + __builtin_amdgcn_mbcnt_hi((uint32_t)(mj >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mj, 0u))] =
-                        lane | ((leaf_first(leaf) + j) << 6);
-                n_leaf += (uint32_t)__builtin_popcountll(mj);
-            }
-            while (n_leaf >= n_act) {
+            if (at_leaf)
+                L.list[n_leaf + __builtin_amdgcn_mbcnt_hi((uint32_t)(ml >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ml, 0u))] =
+                    lane | (leaf << 6);
+            n_leaf += (uint32_t)__builtin_popcountll(ml);
+            while (n_leaf >= n_act) {  // (at most n_act - 1 entries are left over: the list never holds more than 127)
                 n_leaf -= n_act;
+                PT_WSTAT(S, 5, 1);
+                PT_WSTAT(S, 6, n_act);
                 leaf_batch(n_leaf, n_act);
                 const uint32_t k = (uint32_t)(load_key(&L.keys[lane]) >> 32);
                 if (k < 0x7f800000u) bound = __builtin_fminf(best_t, __uint_as_float(k + 1u));
             }
         }
     }
-    if (n_leaf != 0u) leaf_batch(0u, n_leaf);
+    if (n_leaf != 0u) {
+        PT_WSTAT(S, 5, 1);
+        PT_WSTAT(S, 6, n_leaf);
+        leaf_batch(0u, n_leaf);
+    }
     const unsigned long long key = load_key(&L.keys[lane]);
     const uint32_t k = (uint32_t)(key >> 32);
     if (k < 0x7f800000u) {
@@ -1087,6 +1120,72 @@ __device__ __forceinline__ bool walk_deferred(const DevScene &S, vec3 o, vec3 d,
         }
     }
     return tie;
+}
+
+// The candidate scan's form of the two steps above (k_pass_cand<.., BVH>): a ray's state is its key - (distance bits << 32)
+// | visiting rank of the best primitive so far.
+// 1. does the ray have to walk a BVH mesh at all?  Exact gate (mod.rs:267-273), then the first step of the walk with the
+//    root node in SGPRs: boxes farther than the best hit so far (the spheres and the candidate records are done) cannot hold
+//    a winner - a triangle exactly as far is still looked at (hit_boxes prunes on '>' only), ranks decide among equals.
+__device__ __forceinline__ bool bvh_wants(const DevScene &S, vec3 o, vec3 d, float best_t) {
+    bool want = false;
+    const uint32_t n_pairs = (S.n_objs + 1u) >> 1;
+    for (uint32_t p = 0; p < n_pairs; ++p) {
+        const ObjPairRec ob = ld_uniform(S.obj_pairs + p);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int32_t root = ob.bvh_root[hf];
+            if (ob.kind[hf] != kKindMesh || root == kNoBvh) continue;  // wave-uniform
+            const vec3 op = mk(ob.cx[hf], ob.cy[hf], ob.cz[hf]) - o;   // intersect_sphere, mod.rs:413-427
+            const float b = dot(op, d);
+            const float det = (b * b - dot(op, op)) + ob.rr[hf];
+            const float sq = f_sqrt(det);
+            bool pass = !(det < 0.0f) && ((b - sq) >= 1e-4f || (b + sq) >= 1e-4f);
+            if (root >= 0 && __builtin_amdgcn_ballot_w64(pass) != 0ull) {
+                const BvhNode rn = ld_uniform(S.bvh_nodes + root);
+                const float big = 1e18f;
+                const vec3 inv = mk(__builtin_fmaxf(__builtin_fminf(1.0f / d.x, big), -big),
+                                    __builtin_fmaxf(__builtin_fminf(1.0f / d.y, big), -big),
+                                    __builtin_fmaxf(__builtin_fminf(1.0f / d.z, big), -big));
+                bool h0, h1;
+                f32x2 tin;
+                hit_boxes(rn, splat2(inv.x), splat2(inv.y), splat2(inv.z), splat2(o.x * inv.x), splat2(o.y * inv.y),
+                          splat2(o.z * inv.z), best_t, &h0, &h1, &tin);
+                pass = pass && (h0 || h1);
+            }
+            want = want || pass;
+        }
+    }
+    return want;
+}
+// 2. the walks of a parked ray: every BVH mesh in visiting order, exact gate first; the closest triangle of a mesh (the
+//    first in list order among equals: bvh_closest_postponed) enters the key with its rank - one integer minimum is
+//    intersect_scene's strict '<' over the whole visiting sequence (mod.rs:598,649), no tie needs a second look.
+__device__ __forceinline__ unsigned long long walk_deferred_keys(const DevScene &S, vec3 o, vec3 d, uint4 *lds,
+                                                                 unsigned long long key, const LeafLds *leaves) {
+    const uint32_t n_pairs = (S.n_objs + 1u) >> 1;
+    for (uint32_t p = 0; p < n_pairs; ++p) {
+        const ObjPairRec ob = ld_uniform(S.obj_pairs + p);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int32_t root = ob.bvh_root[hf];
+            if (ob.kind[hf] != kKindMesh || root == kNoBvh) continue;  // wave-uniform
+            const vec3 op = mk(ob.cx[hf], ob.cy[hf], ob.cz[hf]) - o;
+            const float b = dot(op, d);
+            const float det = (b * b - dot(op, op)) + ob.rr[hf];
+            const float sq = f_sqrt(det);
+            const bool pass = !(det < 0.0f) && ((b - sq) >= 1e-4f || (b + sq) >= 1e-4f);
+            if (__builtin_amdgcn_ballot_w64(pass) == 0ull) continue;
+            float mt = __builtin_inff();
+            int32_t mid = -1;
+            if (pass) bvh_walk(S, lds, o, d, root, __uint_as_float((uint32_t)(key >> 32)), mt, mid, leaves);
+            if (pass && mid >= 0) {
+                const unsigned long long k2 = ((unsigned long long)__float_as_uint(mt) << 32) | S.tri_rank[mid];
+                key = k2 < key ? k2 : key;
+            }
+        }
+    }
+    return key;
 }
 
 // ---------------------------------------------------------------------------------------------

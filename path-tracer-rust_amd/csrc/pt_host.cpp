@@ -248,6 +248,7 @@ bool flatten_scene(const pt_camera &cam, const pt_object *objs, uint32_t n_objs,
     std::vector<uint8_t> claimed(n_tris, 0);
     bool have_bvh = false;
     out.bvh_pair_base = 0;
+    out.bvh_stack = 0;
     out.bvh_pair_span = 0;
     for (uint32_t i = 0; i < n_objs; ++i) {
         const pt_object &o = objs[i];
@@ -352,7 +353,10 @@ bool flatten_scene(const pt_camera &cam, const pt_object *objs, uint32_t n_objs,
                     bb.use_sah = attempt == 0;
                     vec3 blo, bhi;
                     r.bvh_root = bb.build(0, bt.size(), blo, bhi, 0);
-                    if (bb.depth_max + 2 < kBvhStack) break;
+                    if (bb.depth_max + 2 < kBvhStack) {
+                        out.bvh_stack = std::max(out.bvh_stack, (uint32_t)bb.depth_max + 2u);
+                        break;
+                    }
                     if (attempt == 1) {
                         err = "object " + std::to_string(i) + ": BVH deeper than the traversal stack";
                         return false;
@@ -582,8 +586,9 @@ bool flatten_scene(const pt_camera &cam, const pt_object *objs, uint32_t n_objs,
             for (int hf = 0; hf < 2; ++hf)
                 if (f.pair[hf] != kNoPair) f.pair[hf] += out.n_other_pairs;
         out.cand_pairs.insert(out.cand_pairs.end(), filtered.begin(), filtered.end());
-        out.cand_ok = !have_bvh && out.cand_pairs.size() <= kCandMaxPairs;
+        out.cand_ok = out.cand_pairs.size() <= kCandMaxPairs;
     }
+    out.tri_rank = tri_rank;
     return true;
 }
 

@@ -25,8 +25,11 @@ struct FlatScene {
     std::vector<CandPairRec> cand_pairs;  // [0, n_other_pairs): records without a filter
     std::vector<uint32_t> rank_id;
     std::vector<SurfRec> surf;  // by rank
+    std::vector<uint32_t> tri_rank;  // rank of triangle k (the inverse of rank_id over the triangles)
     uint32_t n_other_pairs = 0;
-    bool cand_ok = false;  // the scene can use the candidate scan (no BVH mesh, records numbered in 9 bits)
+    bool cand_ok = false;  // the scene can use the candidate scan (the records of its meshes without a BVH are numbered in
+                           // 9 bits; meshes with a BVH are walked: k_pass_cand<.., BVH>)
+    uint32_t bvh_stack = 0;      // traversal-stack entries the deepest tree needs (<= kBvhStack)
     uint32_t bvh_pair_base = 0;  // first TriPairRec that is a BVH leaf
     uint32_t bvh_pair_span = 0;  // leaves lie in [bvh_pair_base, bvh_pair_base + bvh_pair_span)
 };

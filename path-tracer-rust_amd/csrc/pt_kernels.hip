@@ -81,6 +81,17 @@ __device__ __forceinline__ void store_ray(const StreamSlice &q, uint32_t slot, v
     *reinterpret_cast<float2 *>(q.od1 + slot * 8u) = make_float2(d.y, d.z);
     *reinterpret_cast<float4 *>(q.tp + slot * 16u) = make_float4(thr.x, thr.y, thr.z, __uint_as_float(word));
 }
+// a ray of a stream's slice (read once per level; non-temporal loads / stores were tried: loads +0.2 %, stores -6 % - the
+// next level reads what this one wrote from L2)
+__device__ __forceinline__ void load_ray_slice(const StreamSlice &q, uint32_t i, vec3 &o, vec3 &d, vec3 &thr, uint32_t &word) {
+    const float4 a = *reinterpret_cast<const float4 *>(q.od0 + i * 16u);
+    const float4 tp = *reinterpret_cast<const float4 *>(q.tp + i * 16u);
+    const float2 c = *reinterpret_cast<const float2 *>(q.od1 + i * 8u);
+    o = mk(a.x, a.y, a.z);
+    d = mk(a.w, c.x, c.y);
+    thr = mk(tp.x, tp.y, tp.z);
+    word = __float_as_uint(tp.w);
+}
 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_generate(FrameParams F, RayQueue q, uint32_t *__restrict__ cnt0,
@@ -484,7 +495,26 @@ __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, R
 // the oldest entries of the ring), so the rays of chunk `it - 1` take their hit from their key, are shaded and appended.
 // One trip beyond the last chunk flushes the ring.  Streams, levels, accumulators and the final flush are k_pass's;
 // glass hits are shaded in place (the deferral buffers' LDS is what the ray slots use here).
-template <bool STAGED, bool DEFER>
+// BVH = true (scenes with BVH meshes): when a ray is finished - its key holds the best of the spheres and of the candidate
+// records - bvh_wants decides whether it has to walk a BVH mesh; such a ray is not shaded but PARKED per wave in LDS
+// (ray index + key, 12 B; the ray stays in the queue, a primary ray is generated again), and 64 parked rays at a time are
+// walked (leaves postponed: bvh_closest_postponed), their triangles folded into the key by rank, shaded and appended.
+// LDS of that form, between the per-wave candidate areas and the staged records:
+//   [traversal stacks: DevScene.bvh_stack x kBlock x u16|u32][per wave: park u32 idx x 128, u64 key x 128][per wave: LeafLds]
+constexpr uint32_t kCandParkCap = 128;  // 63 left over + 64 new at most
+__host__ __device__ inline size_t pass_cand_stack_bytes(const DevScene &S) {
+    return ((size_t)S.bvh_stack * kBlock * ((S.bvh_in_lds & 2u) ? sizeof(uint16_t) : sizeof(uint32_t)) + 15) & ~(size_t)15;
+}
+constexpr size_t kCandParkBytes = kCandParkCap * 12u;                  // per wave
+constexpr size_t kCandLeafBytes = 64u * 8u + kLeafListCap * 4u;        // per wave
+__host__ __device__ inline size_t pass_cand_bvh_bytes(const DevScene &S) {
+    return pass_cand_stack_bytes(S) + (size_t)(kBlock / 64u) * (kCandParkBytes + kCandLeafBytes);
+}
+static_assert(kCandParkBytes % 16u == 0u && kCandLeafBytes % 16u == 0u, "per-wave areas stay 16-byte aligned");
+
+// (The workgroup's own copy of the nodes in LDS, in front of the stacks, was tried: mesh.json's 141 nodes are 9 KB, which
+// leaves room for three workgroups per CU instead of four - 16.1 against 17.8 G bounces/s.)
+template <bool STAGED, bool DEFER, bool BVH>
 __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams F, RayQueue q0, RayQueue q1, uint32_t cap,
                                                          uint32_t s0, uint32_t s_here, uint32_t m,
                                                          unsigned long long *__restrict__ acc,
@@ -507,20 +537,34 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
         cand.keys = reinterpret_cast<unsigned long long *>(wbase + 128u * 16u);
         cand.ray_b = reinterpret_cast<float2 *>(wbase + 128u * 24u);
         cand.queue = reinterpret_cast<uint16_t *>(wbase + 128u * 32u);
-        char *sbase = cbase + pass_lds_cand_bytes();
+        char *sbase = cbase + pass_lds_cand_bytes() + (BVH ? pass_cand_bvh_bytes(S) : 0u);
         cand.staged = reinterpret_cast<const CandPairRec *>(sbase);
         cand.surf = S.surf;
-        if (STAGED) {  // the workgroup's own copies of the candidate records and of the shading records
+        if (STAGED) {  // the workgroup's own copies of the candidate records and (while they fit) of the shading records
             const uint4 *src = reinterpret_cast<const uint4 *>(S.cand_pairs);
             uint4 *dst = reinterpret_cast<uint4 *>(sbase);
             const uint32_t n_rows = S.n_cand_pairs * (uint32_t)(sizeof(CandPairRec) / 16u);
             for (uint32_t k = tid; k < n_rows; k += kBlock) dst[k] = src[k];
-            const uint4 *src2 = reinterpret_cast<const uint4 *>(S.surf);
-            uint4 *dst2 = dst + n_rows;
-            const uint32_t n_rows2 = (S.n_objs + S.n_tris) * (uint32_t)(sizeof(SurfRec) / 16u);
-            for (uint32_t k = tid; k < n_rows2; k += kBlock) dst2[k] = src2[k];
-            cand.surf = reinterpret_cast<const SurfRec *>(dst2);
+            if (!BVH || S.surf_staged) {  // wave-uniform
+                const uint4 *src2 = reinterpret_cast<const uint4 *>(S.surf);
+                uint4 *dst2 = dst + n_rows;
+                const uint32_t n_rows2 = (S.n_objs + S.n_tris) * (uint32_t)(sizeof(SurfRec) / 16u);
+                for (uint32_t k = tid; k < n_rows2; k += kBlock) dst2[k] = src2[k];
+                cand.surf = reinterpret_cast<const SurfRec *>(dst2);
+            }
         }
+    }
+    // BVH: traversal stacks of the workgroup, then this wave's parking area and leaf list
+    uint4 *const stacks = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(dyn_lds) + pass_lds_cand_offset(m, DEFER) + pass_lds_cand_bytes());
+    uint32_t *p_idx = nullptr;
+    unsigned long long *p_key = nullptr;
+    LeafLds leaves{};
+    if (BVH) {
+        char *wb = reinterpret_cast<char *>(stacks) + pass_cand_stack_bytes(S) + (size_t)(tid >> 6) * (kCandParkBytes + kCandLeafBytes);
+        p_key = reinterpret_cast<unsigned long long *>(wb);
+        p_idx = reinterpret_cast<uint32_t *>(wb + kCandParkCap * 8u);
+        leaves.keys = reinterpret_cast<unsigned long long *>(wb + kCandParkBytes);
+        leaves.list = reinterpret_cast<uint32_t *>(wb + kCandParkBytes + 64u * 8u);
     }
     const size_t base = (size_t)b * cap;
     ShadeParams P;
@@ -589,11 +633,43 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
         }
         append(so, word);
     };
+    // BVH: 64 parked rays (or the rest of a level): the ray again, its walks, shading, appending
+    StreamSlice qin{};
+    uint32_t level = 0;
+    uint32_t n_park = 0;  // wave-uniform
+    auto walk_batch = [&](uint32_t e, bool valid) {
+        ShadeOut so;
+        so.n_rays = 0;
+        so.emits = false;
+        uint32_t word = 0;
+        if (valid) {
+            const uint32_t i = p_idx[e];
+            PathRay in;
+            if (level == 0u) {
+                const uint32_t pj = i % mb, sj = i / mb;
+                in = primary_ray(F, lds_pix[pj], s0 + sj);
+                word = pack_word(pj, sj, 0u, 1u);
+            } else {
+                load_ray_slice(qin, i, in.o, in.d, in.thr, word);
+            }
+            const unsigned long long key = walk_deferred_keys(S, in.o, in.d, stacks, p_key[e], &leaves);
+            const uint32_t rank = (uint32_t)key;
+            if (rank != 0xffffffffu) {
+                in.pix = lds_pix[word_pix(word)];
+                in.meta = pack_meta(s0 + word_sample(word), word_depth(word), word_branch(word));
+                const Surface sf = fetch_surface_rank(cand.surf, in.o, in.d, __uint_as_float((uint32_t)(key >> 32)), rank);
+                shade_surface<kShadeAll>(P, in, sf, so);
+                if (so.emits) add_radiance_lds(lds_acc, m, word_pix(word), so.contrib);
+            }
+        }
+        append(so, word);
+    };
     CandRing ring;
     ring.head = 0u;
     ring.count = 0u;
     for (uint32_t depth = 0; depth < (uint32_t)kMaxDepth && n != 0u; ++depth) {
-        const StreamSlice qin = slice_of((depth & 1u) ? q1 : q0, base);  // level 0 is never stored
+        qin = slice_of((depth & 1u) ? q1 : q0, base);  // level 0 is never stored
+        level = depth;
         qout = slice_of((depth & 1u) ? q0 : q1, base);
         __syncthreads();  // level `depth` of the stream is complete and visible (and, the first time, the staged records)
         if (tid == 0) s_tail_p[(depth + 1u) & 1u] = 0u;
@@ -620,13 +696,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
                         in = primary_ray(F, lds_pix[pj], s0 + sj);
                         word = pack_word(pj, sj, 0u, 1u);
                     } else {
-                        const float4 a = *reinterpret_cast<const float4 *>(qin.od0 + i * 16u);
-                        const float4 tp = *reinterpret_cast<const float4 *>(qin.tp + i * 16u);
-                        const float2 c = *reinterpret_cast<const float2 *>(qin.od1 + i * 8u);
-                        in.o = mk(a.x, a.y, a.z);
-                        in.d = mk(a.w, c.x, c.y);
-                        in.thr = mk(tp.x, tp.y, tp.z);
-                        word = __float_as_uint(tp.w);
+                        load_ray_slice(qin, i, in.o, in.d, in.thr, word);
                     }
                 }
                 cur_thr = in.thr;
@@ -652,17 +722,29 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
                 uint32_t hit_rank = 0xffffffffu;
                 PathRay pr;
                 pr.o = pr.d = pr.thr = mk(0.0f, 0.0f, 0.0f);
+                bool park = false;
+                unsigned long long park_key = 0ull;
                 if (prev_valid) {
                     const uint32_t slot = ((par ^ 1u) << 6) | lane;
                     const unsigned long long key = load_key(&cand.keys[slot]);
                     const uint32_t rank = (uint32_t)key;
-                    if (rank != 0xffffffffu) {
-                        hit_t = __uint_as_float((uint32_t)(key >> 32));
-                        hit_rank = rank;
+                    if (BVH) {  // (a miss so far may still hit a BVH mesh)
                         const float4 ra = cand.ray_a[slot];
                         const float2 rb = cand.ray_b[slot];
                         pr.o = mk(ra.x, ra.y, ra.z);
                         pr.d = mk(ra.w, rb.x, rb.y);
+                        park = bvh_wants(S, pr.o, pr.d, __uint_as_float((uint32_t)(key >> 32)));
+                        park_key = key;
+                    }
+                    if (rank != 0xffffffffu && !park) {
+                        hit_t = __uint_as_float((uint32_t)(key >> 32));
+                        hit_rank = rank;
+                        if (!BVH) {
+                            const float4 ra = cand.ray_a[slot];
+                            const float2 rb = cand.ray_b[slot];
+                            pr.o = mk(ra.x, ra.y, ra.z);
+                            pr.d = mk(ra.w, rb.x, rb.y);
+                        }
                         pr.thr = prev_thr;
                         pr.pix = lds_pix[word_pix(prev_word)];
                         pr.meta = pack_meta(s0 + word_sample(prev_word), word_depth(prev_word), word_branch(prev_word));
@@ -672,6 +754,24 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
                     }
                 }
                 append(so, prev_word);
+                if (BVH) {
+                    const uint64_t mw = __builtin_amdgcn_ballot_w64(park);
+                    PT_WSTAT(S, 7, __builtin_popcountll(__builtin_amdgcn_ballot_w64(prev_valid)));  // rays
+                    PT_WSTAT(S, 8, __builtin_popcountll(mw));                                       // parked
+                    PT_WSTAT(S, 9, 1);
+                    if (mw != 0ull) {
+                        if (park) {
+                            const uint32_t e = n_park + lane_prefix(mw);
+                            p_idx[e] = (it - 1u) * kBlock + tid;
+                            p_key[e] = park_key;
+                        }
+                        n_park += (uint32_t)__builtin_popcountll(mw);
+                    }
+                    if (n_park >= 64u) {  // wave-uniform
+                        n_park -= 64u;
+                        walk_batch(n_park + lane, true);
+                    }
+                }
                 const uint64_t md = DEFER ? __builtin_amdgcn_ballot_w64(so.deferred) : 0ull;
                 if (DEFER && md != 0ull) {
                     if (so.deferred) {
@@ -691,6 +791,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
             prev_thr = cur_thr;
             prev_word = word;
             prev_valid = cur_valid;
+        }
+        if (BVH && n_park != 0u) {  // the rest of this wave's parked rays of the level (the next level reuses the queue slice)
+            walk_batch(lane, lane < n_park);
+            n_park = 0u;
         }
         if (DEFER && n_defer != 0u) {  // the rest of this wave's glass hits of the level (k_pass: carrying them over loses)
             shade_deferred(lane, lane < n_defer);
@@ -864,6 +968,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_bvh(DevScene S, FrameParams 
             }
             shade_and_append(i < n && !want, in, word, h);
             const uint64_t mw = __builtin_amdgcn_ballot_w64(want);
+            PT_WSTAT(S, 7, __builtin_popcountll(__builtin_amdgcn_ballot_w64(i < n)));  // rays
+            PT_WSTAT(S, 8, __builtin_popcountll(mw));                                  // parked
+            PT_WSTAT(S, 9, 1);                                                         // scan trips of a wave
             if (mw != 0ull) {
                 if (want) {
                     const uint32_t e = n_park + lane_prefix(mw);
@@ -1232,21 +1339,33 @@ void launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const FrameParam
         // candidate scan: ray slots, keys and ring per wave, the (smaller) deferral buffers while four workgroups still fit
         // a CU (40 KiB each; the kernel is built for four waves per SIMD), + the workgroup's copy of the candidate records
         const size_t budget = 40u * 1024u;
-        const size_t recs = (size_t)S.n_cand_pairs * sizeof(CandPairRec) + (size_t)(S.n_objs + S.n_tris) * sizeof(SurfRec);
-        const bool defer = pass_lds_cand_offset(m, true) + pass_lds_cand_bytes() <= budget;
-        const size_t before = pass_lds_cand_offset(m, defer) + pass_lds_cand_bytes();
-        const bool staged = before + recs <= budget;
-        const size_t lds = before + (staged ? recs : 0u);
-#define PT_LAUNCH_CAND(ST, DF)                                                                                         \
-    hipLaunchKernelGGL((k_pass_cand<ST, DF>), dim3(K), dim3(kBlock), lds, st, S, F, q0, q1, cap, s0, s_here, m, acc, blk_rays, flags)
-        if (staged && defer)
-            PT_LAUNCH_CAND(true, true);
+        const bool bvh = S.n_bvh_nodes != 0u;
+        DevScene S2 = S;
+        S2.bvh_in_lds &= ~1u;  // (nodes from global memory: PT_BVH_LDS asks for the staged k_intersect, not for this kernel)
+        const size_t walk = bvh ? pass_cand_bvh_bytes(S2) : 0u;
+        const size_t rec_cand = (size_t)S.n_cand_pairs * sizeof(CandPairRec);
+        const size_t rec_surf = (size_t)(S.n_objs + S.n_tris) * sizeof(SurfRec);
+        // glass deferral: not with walks (their stacks take its place; a walked ray is shaded in place anyway)
+        const bool defer = !bvh && pass_lds_cand_offset(m, true) + pass_lds_cand_bytes() <= budget;
+        const size_t before = pass_lds_cand_offset(m, defer) + pass_lds_cand_bytes() + walk;
+        S2.surf_staged = before + rec_cand + rec_surf <= budget ? 1u : 0u;
+        // (without walks the records are staged whole or not at all; with walks the candidate records alone may be)
+        const bool staged = bvh ? (S2.surf_staged || before + rec_cand <= budget + 8u * 1024u) : S2.surf_staged != 0u;
+        const size_t lds = before + (staged ? rec_cand + (S2.surf_staged ? rec_surf : 0u) : 0u);
+#define PT_LAUNCH_CAND(ST, DF, BV)                                                                                     \
+    hipLaunchKernelGGL((k_pass_cand<ST, DF, BV>), dim3(K), dim3(kBlock), lds, st, S2, F, q0, q1, cap, s0, s_here, m, acc, blk_rays, flags)
+        if (bvh && staged)
+            PT_LAUNCH_CAND(true, false, true);
+        else if (bvh)
+            PT_LAUNCH_CAND(false, false, true);
+        else if (staged && defer)
+            PT_LAUNCH_CAND(true, true, false);
         else if (staged)
-            PT_LAUNCH_CAND(true, false);
+            PT_LAUNCH_CAND(true, false, false);
         else if (defer)
-            PT_LAUNCH_CAND(false, true);
+            PT_LAUNCH_CAND(false, true, false);
         else
-            PT_LAUNCH_CAND(false, false);
+            PT_LAUNCH_CAND(false, false, false);
 #undef PT_LAUNCH_CAND
         return;
     }
