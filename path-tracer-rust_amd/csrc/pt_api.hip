@@ -109,6 +109,7 @@ struct pt_ctx {
     DevBuf<CandPairRec> d_cand;
     DevBuf<uint32_t> d_rank_id;
     DevBuf<uint32_t> d_tri_rank;
+    DevBuf<BvhMeshRec> d_bvh_meshes;
     DevBuf<SurfRec> d_surf;
     bool cand_ok = false;
     uint32_t n_bvh_nodes = 0;
@@ -249,10 +250,11 @@ hipEvent_t get_event(pt_ctx *c, size_t i) {
 }
 
 // does a frame with these flags run the candidate scan (k_pass_cand)?  Scenes with BVH meshes: with parked walks, unless
-// their nodes are staged in LDS (PT_BVH_LDS=1) or PT_CAND_BVH=0 asks for k_pass_bvh.
+// their nodes are staged in LDS (PT_BVH_LDS=1), their child references need more than 16 bits (32 768 nodes or leaves)
+// or PT_CAND_BVH=0 asks for k_pass_bvh.
 static uint32_t cand_scan_for(const pt_ctx *c, uint32_t flags) {
     if (!c->tune.cand_scan || !c->cand_ok || (flags & PT_FLAG_NO_BVH)) return 0u;
-    if (c->n_bvh_nodes != 0u && (!c->tune.cand_bvh || (c->scene.bvh_in_lds & 1u))) return 0u;
+    if (c->n_bvh_nodes != 0u && (!c->tune.cand_bvh || (c->scene.bvh_in_lds & 3u) != 2u)) return 0u;  // (16-bit child references)
     return 1u;
 }
 
@@ -622,6 +624,7 @@ void pt_ctx_destroy(pt_ctx *c) {
     c->d_cand.release();
     c->d_rank_id.release();
     c->d_tri_rank.release();
+    c->d_bvh_meshes.release();
     c->d_surf.release();
     c->d_boxes.release();
     c->q_o.release();
@@ -665,7 +668,7 @@ int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uin
         (rc = c->d_nodes.ensure(fs.bvh_nodes.size())) || (rc = c->d_sph.ensure(fs.sph_pairs.size())) ||
         (rc = c->d_flat.ensure(fs.flat_pairs.size())) || (rc = c->d_cand.ensure(fs.cand_pairs.size())) ||
         (rc = c->d_rank_id.ensure(fs.rank_id.size())) || (rc = c->d_surf.ensure(fs.surf.size())) ||
-        (rc = c->d_tri_rank.ensure(fs.tri_rank.size())))
+        (rc = c->d_tri_rank.ensure(fs.tri_rank.size())) || (rc = c->d_bvh_meshes.ensure(fs.bvh_meshes.size())))
         return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (!fs.objs.empty())
@@ -698,6 +701,10 @@ int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uin
     HIP_TRY(hipMemcpy(c->d_tri_rank.p, fs.tri_rank.data(), fs.tri_rank.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     c->scene.rank_id = c->d_rank_id.p;
     c->scene.tri_rank = c->d_tri_rank.p;
+    if (!fs.bvh_meshes.empty())
+        HIP_TRY(hipMemcpy(c->d_bvh_meshes.p, fs.bvh_meshes.data(), fs.bvh_meshes.size() * sizeof(BvhMeshRec), hipMemcpyHostToDevice));
+    c->scene.bvh_meshes = c->d_bvh_meshes.p;
+    c->scene.n_bvh_meshes = (uint32_t)fs.bvh_meshes.size();
     c->scene.surf = c->d_surf.p;
     c->scene.n_sph_pairs = (uint32_t)fs.sph_pairs.size();
     c->scene.n_flat_pairs = (uint32_t)fs.flat_pairs.size();

@@ -164,6 +164,14 @@ struct alignas(16) TriShade {
     uint32_t owner;    // object index
 };
 
+// a mesh that has a BVH, in intersect_scene's visiting order (k_pass_cand: gate + walk per entry)
+struct alignas(16) BvhMeshRec {
+    float cx, cy, cz, rr;  // bounding sphere in world space, radius squared
+    int32_t root;          // node index (>= 0) or a leaf reference (< 0: the whole mesh is one leaf)
+    uint32_t pad[3];
+};
+static_assert(sizeof(BvhMeshRec) == 32, "BvhMeshRec layout");
+
 struct DevScene {
     const ObjRec *objs;
     const ObjPairRec *obj_pairs;  // ceil(n_objs / 2) records
@@ -190,6 +198,8 @@ struct DevScene {
     const uint32_t *rank_id;        // [n_objs + n_tris]
     const SurfRec *surf;            // [n_objs + n_tris], by rank
     const uint32_t *tri_rank;       // [n_tris]: rank of a triangle (BVH walks report triangle indices)
+    const BvhMeshRec *bvh_meshes;   // [n_bvh_meshes], visiting order
+    uint32_t n_bvh_meshes;
     uint32_t n_sph_pairs, n_flat_pairs, n_cand_pairs;
     uint32_t n_other_pairs;         // cand_pairs [0, n_other_pairs) have no filter: candidates for every ray
     uint32_t cand_scan;             // 1: k_pass uses the candidate scan
@@ -495,6 +505,22 @@ struct Stack32 {
     __device__ __forceinline__ T enc(int32_t r) const { return (T)r; }
     __device__ __forceinline__ int32_t dec(T e) const { return (int32_t)e; }
 };
+// Either width, chosen at run time by a wave-uniform flag (DevScene.bvh_in_lds bit 1): one copy of the walk in the kernel
+// instead of one per width.  `at` is a byte address in the lane's stack column.
+struct StackDyn {
+    bool narrow;
+    Stack16 c16;
+    __device__ __forceinline__ uint32_t entry_bytes() const { return narrow ? 2u : 4u; }
+    __device__ __forceinline__ void store(char *at, int32_t r) const {
+        if (narrow)
+            *reinterpret_cast<uint16_t *>(at) = c16.enc(r);
+        else
+            *reinterpret_cast<int32_t *>(at) = r;
+    }
+    __device__ __forceinline__ int32_t load(const char *at) const {
+        return narrow ? c16.dec(*reinterpret_cast<const uint16_t *>(at)) : *reinterpret_cast<const int32_t *>(at);
+    }
+};
 
 // Closest triangle of one BVH mesh for one lane.  `nodes` is LDS (staged) or global memory; `stack` is this
 // lane's column of the workgroup's LDS stack (stride `stride`).  Only triangles that could beat `best_t`
@@ -581,13 +607,15 @@ __device__ __forceinline__ unsigned long long load_key(const unsigned long long 
 struct LeafLds {
     unsigned long long *keys;  // [64] of this wave
     uint32_t *list;            // [kLeafListCap] of this wave: lane | leaf code << 6 (leaf_first / leaf_count)
+    bool narrow_only;          // the caller only runs scenes whose child references fit 16 bits (k_pass_cand)
 };
 constexpr uint32_t kLeafListCap = 128u;  // < 64 left over + at most 64 leaves appended by one step
 
-template <class NodePtr, class Codec>
-__device__ __forceinline__ void bvh_closest_postponed(const DevScene &S, NodePtr nodes, Codec codec, typename Codec::T *stack,
+template <class NodePtr>
+__device__ __forceinline__ void bvh_closest_postponed(const DevScene &S, NodePtr nodes, StackDyn codec, char *stack,
                                                       uint32_t stride, const LeafLds &L, vec3 o, vec3 d, int32_t root,
                                                       float best_t, float &mt, int32_t &mid) {
+    // `stack`: this lane's column of the workgroup's stacks (byte address of entry 0), `stride`: bytes between entries
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t act = __builtin_amdgcn_ballot_w64(true);
     const uint32_t n_act = (uint32_t)__builtin_popcountll(act);
@@ -630,67 +658,68 @@ __device__ __forceinline__ void bvh_closest_postponed(const DevScene &S, NodePtr
         }
     };
     uint32_t sp = 0;
-    typename Codec::T *top = stack;  // &stack[sp * stride]: this lane's column of the workgroup's stacks
+    char *top = stack;  // entry sp of this lane's column
     int32_t cur = root;
     PT_WSTAT(S, 0, n_act);  // walks
     PT_WSTAT(S, 10, 1);     // wave-walks
     for (;;) {  // wave-uniform loop: every lane that still has work takes one step per trip
-        if (__builtin_amdgcn_ballot_w64(cur != kDone) == 0ull) break;
-        PT_WSTAT(S, 1, 1);                                                                              // trips
-        PT_WSTAT(S, 2, __builtin_popcountll(__builtin_amdgcn_ballot_w64(cur != kDone)));                // lanes with work
-        PT_WSTAT(S, 3, __builtin_popcountll(__builtin_amdgcn_ballot_w64(cur >= 0)));                    // node steps
-        bool at_leaf = false, pop = false;
-        uint32_t leaf = 0;
-        if (cur >= 0) {
-            const BvhNode n = nodes[cur];
-            bool h0, h1;
-            f32x2 tin;
-            hit_boxes(n, ivx, ivy, ivz, oix, oiy, oiz, bound, &h0, &h1, &tin);
-            const bool first0 = tin[0] <= tin[1];
-            if (h0 && h1) {
-                if (sp < S.bvh_stack) *top = codec.enc(first0 ? n.c[1] : n.c[0]);
-                ++sp;  // (the host guarantees tree depth < DevScene.bvh_stack <= kBvhStack)
-                top += stride;
-                cur = first0 ? n.c[0] : n.c[1];
-            } else if (h0 || h1) {
-                cur = h0 ? n.c[0] : n.c[1];
-            } else {
+        const bool walking = __builtin_amdgcn_ballot_w64(cur != kDone) != 0ull;
+        if (!walking && n_leaf == 0u) break;
+        if (walking) {
+            PT_WSTAT(S, 1, 1);                                                                              // trips
+            PT_WSTAT(S, 2, __builtin_popcountll(__builtin_amdgcn_ballot_w64(cur != kDone)));                // lanes with work
+            PT_WSTAT(S, 3, __builtin_popcountll(__builtin_amdgcn_ballot_w64(cur >= 0)));                    // node steps
+            bool at_leaf = false, pop = false;
+            uint32_t leaf = 0;
+            if (cur >= 0) {
+                const BvhNode n = nodes[cur];
+                bool h0, h1;
+                f32x2 tin;
+                hit_boxes(n, ivx, ivy, ivz, oix, oiy, oiz, bound, &h0, &h1, &tin);
+                const bool first0 = tin[0] <= tin[1];
+                if (h0 && h1) {
+                    if (sp < S.bvh_stack) codec.store(top, first0 ? n.c[1] : n.c[0]);
+                    ++sp;  // (the host guarantees tree depth < DevScene.bvh_stack <= kBvhStack)
+                    top += stride;
+                    cur = first0 ? n.c[0] : n.c[1];
+                } else if (h0 || h1) {
+                    cur = h0 ? n.c[0] : n.c[1];
+                } else {
+                    pop = true;
+                }
+            } else if (cur != kDone) {
+                at_leaf = true;
+                leaf = (uint32_t)~cur;
                 pop = true;
             }
-        } else if (cur != kDone) {
-            at_leaf = true;
-            leaf = (uint32_t)~cur;
-            pop = true;
-        }
-        if (pop) {  // one place for both: nothing below this node / the leaf is on the list
-            if (sp == 0u) {
-                cur = kDone;
-            } else {
-                --sp;
-                top -= stride;
-                cur = codec.dec(*top);
+            if (pop) {  // one place for both: nothing below this node / the leaf is on the list
+                if (sp == 0u) {
+                    cur = kDone;
+                } else {
+                    --sp;
+                    top -= stride;
+                    cur = codec.load(top);
+                }
+            }
+            const uint64_t ml = __builtin_amdgcn_ballot_w64(at_leaf);
+            if (ml != 0ull) {
+                if (at_leaf)
+                    L.list[n_leaf + __builtin_amdgcn_mbcnt_hi((uint32_t)(ml >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ml, 0u))] =
+                        lane | (leaf << 6);
+                n_leaf += (uint32_t)__builtin_popcountll(ml);
             }
         }
-        const uint64_t ml = __builtin_amdgcn_ballot_w64(at_leaf);
-        if (ml != 0ull) {
-            if (at_leaf)
-                L.list[n_leaf + __builtin_amdgcn_mbcnt_hi((uint32_t)(ml >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ml, 0u))] =
-                    lane | (leaf << 6);
-            n_leaf += (uint32_t)__builtin_popcountll(ml);
-            while (n_leaf >= n_act) {  // (at most n_act - 1 entries are left over: the list never holds more than 127)
-                n_leaf -= n_act;
-                PT_WSTAT(S, 5, 1);
-                PT_WSTAT(S, 6, n_act);
-                leaf_batch(n_leaf, n_act);
-                const uint32_t k = (uint32_t)(load_key(&L.keys[lane]) >> 32);
-                if (k < 0x7f800000u) bound = __builtin_fminf(best_t, __uint_as_float(k + 1u));
-            }
+        // a dense batch whenever as many leaves wait as the wave has walking lanes; what is left when the walks are over
+        // (at most n_act - 1 entries are ever left over: the list never holds more than 127)
+        while (n_leaf >= n_act || (!walking && n_leaf != 0u)) {
+            const uint32_t cnt = n_leaf < n_act ? n_leaf : n_act;
+            n_leaf -= cnt;
+            PT_WSTAT(S, 5, 1);
+            PT_WSTAT(S, 6, cnt);
+            leaf_batch(n_leaf, cnt);
+            const uint32_t k = (uint32_t)(load_key(&L.keys[lane]) >> 32);
+            if (k < 0x7f800000u) bound = __builtin_fminf(best_t, __uint_as_float(k + 1u));
         }
-    }
-    if (n_leaf != 0u) {
-        PT_WSTAT(S, 5, 1);
-        PT_WSTAT(S, 6, n_leaf);
-        leaf_batch(0u, n_leaf);
     }
     const unsigned long long key = load_key(&L.keys[lane]);
     const uint32_t k = (uint32_t)(key >> 32);
@@ -720,16 +749,13 @@ __host__ __device__ inline size_t bvh_lds_bytes(const DevScene &S, uint32_t bloc
 __device__ __forceinline__ void bvh_walk(const DevScene &S, uint4 *lds, vec3 o, vec3 d, int32_t root, float best_t,
                                          float &mt, int32_t &mid, const LeafLds *leaves = nullptr) {
     uint4 *const stacks = (S.bvh_in_lds & 1u) ? lds + S.n_bvh_nodes * 4u : lds;
-    if (leaves) {  // k_pass_bvh: nodes in global memory, leaves postponed
-        if (S.bvh_in_lds & 2u) {
-            Stack16 codec;
-            codec.pair_base = S.bvh_pair_base;
-            bvh_closest_postponed(S, S.bvh_nodes, codec, reinterpret_cast<uint16_t *>(stacks) + threadIdx.x, blockDim.x, *leaves,
-                                  o, d, root, best_t, mt, mid);
-        } else {
-            bvh_closest_postponed(S, S.bvh_nodes, Stack32(), reinterpret_cast<uint32_t *>(stacks) + threadIdx.x, blockDim.x,
-                                  *leaves, o, d, root, best_t, mt, mid);
-        }
+    if (leaves) {  // k_pass_bvh, k_pass_cand: nodes in global memory, leaves postponed
+        StackDyn codec;
+        codec.narrow = leaves->narrow_only || (S.bvh_in_lds & 2u) != 0u;  // (a literal `true` folds the other width away)
+        codec.c16.pair_base = S.bvh_pair_base;
+        const uint32_t eb = codec.entry_bytes();
+        bvh_closest_postponed(S, S.bvh_nodes, codec, reinterpret_cast<char *>(stacks) + threadIdx.x * eb, blockDim.x * eb, *leaves,
+                              o, d, root, best_t, mt, mid);
         return;
     }
     if (S.bvh_in_lds & 2u) {
@@ -1129,32 +1155,26 @@ __device__ __forceinline__ bool walk_deferred(const DevScene &S, vec3 o, vec3 d,
 //    a winner - a triangle exactly as far is still looked at (hit_boxes prunes on '>' only), ranks decide among equals.
 __device__ __forceinline__ bool bvh_wants(const DevScene &S, vec3 o, vec3 d, float best_t) {
     bool want = false;
-    const uint32_t n_pairs = (S.n_objs + 1u) >> 1;
-    for (uint32_t p = 0; p < n_pairs; ++p) {
-        const ObjPairRec ob = ld_uniform(S.obj_pairs + p);
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            const int32_t root = ob.bvh_root[hf];
-            if (ob.kind[hf] != kKindMesh || root == kNoBvh) continue;  // wave-uniform
-            const vec3 op = mk(ob.cx[hf], ob.cy[hf], ob.cz[hf]) - o;   // intersect_sphere, mod.rs:413-427
-            const float b = dot(op, d);
-            const float det = (b * b - dot(op, op)) + ob.rr[hf];
-            const float sq = f_sqrt(det);
-            bool pass = !(det < 0.0f) && ((b - sq) >= 1e-4f || (b + sq) >= 1e-4f);
-            if (root >= 0 && __builtin_amdgcn_ballot_w64(pass) != 0ull) {
-                const BvhNode rn = ld_uniform(S.bvh_nodes + root);
-                const float big = 1e18f;
-                const vec3 inv = mk(__builtin_fmaxf(__builtin_fminf(1.0f / d.x, big), -big),
-                                    __builtin_fmaxf(__builtin_fminf(1.0f / d.y, big), -big),
-                                    __builtin_fmaxf(__builtin_fminf(1.0f / d.z, big), -big));
-                bool h0, h1;
-                f32x2 tin;
-                hit_boxes(rn, splat2(inv.x), splat2(inv.y), splat2(inv.z), splat2(o.x * inv.x), splat2(o.y * inv.y),
-                          splat2(o.z * inv.z), best_t, &h0, &h1, &tin);
-                pass = pass && (h0 || h1);
-            }
-            want = want || pass;
+    for (uint32_t q = 0; q < S.n_bvh_meshes; ++q) {
+        const BvhMeshRec bm = ld_uniform(S.bvh_meshes + q);
+        const vec3 op = mk(bm.cx, bm.cy, bm.cz) - o;  // intersect_sphere, mod.rs:413-427
+        const float b = dot(op, d);
+        const float det = (b * b - dot(op, op)) + bm.rr;
+        const float sq = f_sqrt(det);
+        bool pass = !(det < 0.0f) && ((b - sq) >= 1e-4f || (b + sq) >= 1e-4f);
+        if (bm.root >= 0 && __builtin_amdgcn_ballot_w64(pass) != 0ull) {
+            const BvhNode rn = ld_uniform(S.bvh_nodes + bm.root);
+            const float big = 1e18f;
+            const vec3 inv = mk(__builtin_fmaxf(__builtin_fminf(1.0f / d.x, big), -big),
+                                __builtin_fmaxf(__builtin_fminf(1.0f / d.y, big), -big),
+                                __builtin_fmaxf(__builtin_fminf(1.0f / d.z, big), -big));
+            bool h0, h1;
+            f32x2 tin;
+            hit_boxes(rn, splat2(inv.x), splat2(inv.y), splat2(inv.z), splat2(o.x * inv.x), splat2(o.y * inv.y),
+                      splat2(o.z * inv.z), best_t, &h0, &h1, &tin);
+            pass = pass && (h0 || h1);
         }
+        want = want || pass;
     }
     return want;
 }
@@ -1163,26 +1183,20 @@ __device__ __forceinline__ bool bvh_wants(const DevScene &S, vec3 o, vec3 d, flo
 //    intersect_scene's strict '<' over the whole visiting sequence (mod.rs:598,649), no tie needs a second look.
 __device__ __forceinline__ unsigned long long walk_deferred_keys(const DevScene &S, vec3 o, vec3 d, uint4 *lds,
                                                                  unsigned long long key, const LeafLds *leaves) {
-    const uint32_t n_pairs = (S.n_objs + 1u) >> 1;
-    for (uint32_t p = 0; p < n_pairs; ++p) {
-        const ObjPairRec ob = ld_uniform(S.obj_pairs + p);
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            const int32_t root = ob.bvh_root[hf];
-            if (ob.kind[hf] != kKindMesh || root == kNoBvh) continue;  // wave-uniform
-            const vec3 op = mk(ob.cx[hf], ob.cy[hf], ob.cz[hf]) - o;
-            const float b = dot(op, d);
-            const float det = (b * b - dot(op, op)) + ob.rr[hf];
-            const float sq = f_sqrt(det);
-            const bool pass = !(det < 0.0f) && ((b - sq) >= 1e-4f || (b + sq) >= 1e-4f);
-            if (__builtin_amdgcn_ballot_w64(pass) == 0ull) continue;
-            float mt = __builtin_inff();
-            int32_t mid = -1;
-            if (pass) bvh_walk(S, lds, o, d, root, __uint_as_float((uint32_t)(key >> 32)), mt, mid, leaves);
-            if (pass && mid >= 0) {
-                const unsigned long long k2 = ((unsigned long long)__float_as_uint(mt) << 32) | S.tri_rank[mid];
-                key = k2 < key ? k2 : key;
-            }
+    for (uint32_t q = 0; q < S.n_bvh_meshes; ++q) {
+        const BvhMeshRec bm = ld_uniform(S.bvh_meshes + q);
+        const vec3 op = mk(bm.cx, bm.cy, bm.cz) - o;
+        const float b = dot(op, d);
+        const float det = (b * b - dot(op, op)) + bm.rr;
+        const float sq = f_sqrt(det);
+        const bool pass = !(det < 0.0f) && ((b - sq) >= 1e-4f || (b + sq) >= 1e-4f);
+        if (__builtin_amdgcn_ballot_w64(pass) == 0ull) continue;
+        float mt = __builtin_inff();
+        int32_t mid = -1;
+        if (pass) bvh_walk(S, lds, o, d, bm.root, __uint_as_float((uint32_t)(key >> 32)), mt, mid, leaves);
+        if (pass && mid >= 0) {
+            const unsigned long long k2 = ((unsigned long long)__float_as_uint(mt) << 32) | S.tri_rank[mid];
+            key = k2 < key ? k2 : key;
         }
     }
     return key;

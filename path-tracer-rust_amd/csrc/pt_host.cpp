@@ -589,6 +589,15 @@ bool flatten_scene(const pt_camera &cam, const pt_object *objs, uint32_t n_objs,
         out.cand_ok = out.cand_pairs.size() <= kCandMaxPairs;
     }
     out.tri_rank = tri_rank;
+    out.bvh_meshes.clear();
+    for (uint32_t v = 0; v < n_objs; ++v) {
+        const ObjRec &r = out.objs[n_objs - 1u - v];
+        if (r.kind != kKindMesh || r.bvh_root == kNoBvh) continue;
+        BvhMeshRec bm{};
+        bm.cx = r.cx, bm.cy = r.cy, bm.cz = r.cz, bm.rr = r.rr;
+        bm.root = r.bvh_root;
+        out.bvh_meshes.push_back(bm);
+    }
     return true;
 }
 

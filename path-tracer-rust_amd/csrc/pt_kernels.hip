@@ -565,6 +565,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
         p_idx = reinterpret_cast<uint32_t *>(wb + kCandParkCap * 8u);
         leaves.keys = reinterpret_cast<unsigned long long *>(wb + kCandParkBytes);
         leaves.list = reinterpret_cast<uint32_t *>(wb + kCandParkBytes + 64u * 8u);
+        leaves.narrow_only = true;  // (launch_pass: scenes with wider references run k_pass_bvh)
     }
     const size_t base = (size_t)b * cap;
     ShadeParams P;
@@ -767,9 +768,12 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
                         }
                         n_park += (uint32_t)__builtin_popcountll(mw);
                     }
-                    if (n_park >= 64u) {  // wave-uniform
-                        n_park -= 64u;
-                        walk_batch(n_park + lane, true);
+                    // 64 parked rays make a batch; the last trip of a level takes what is left (the next level reuses
+                    // the queue slice the rays are read from)
+                    while (n_park >= 64u || (it == n_chunks && n_park != 0u)) {  // wave-uniform
+                        const uint32_t cnt = n_park < 64u ? n_park : 64u;
+                        n_park -= cnt;
+                        walk_batch(n_park + lane, lane < cnt);
                     }
                 }
                 const uint64_t md = DEFER ? __builtin_amdgcn_ballot_w64(so.deferred) : 0ull;
@@ -791,10 +795,6 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
             prev_thr = cur_thr;
             prev_word = word;
             prev_valid = cur_valid;
-        }
-        if (BVH && n_park != 0u) {  // the rest of this wave's parked rays of the level (the next level reuses the queue slice)
-            walk_batch(lane, lane < n_park);
-            n_park = 0u;
         }
         if (DEFER && n_defer != 0u) {  // the rest of this wave's glass hits of the level (k_pass: carrying them over loses)
             shade_deferred(lane, lane < n_defer);
@@ -859,6 +859,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_bvh(DevScene S, FrameParams 
         char *lbase = reinterpret_cast<char *>(dyn_lds) + pass_bvh_leaf_offset(S, m) + (size_t)(tid >> 6) * (64u * 8u + kLeafListCap * 4u);
         leaves.keys = reinterpret_cast<unsigned long long *>(lbase);
         leaves.list = reinterpret_cast<uint32_t *>(lbase + 64u * 8u);
+        leaves.narrow_only = false;
     }
     const size_t base = (size_t)b * cap;
     ShadeParams P;
