@@ -729,6 +729,177 @@ __device__ __forceinline__ void bvh_closest_postponed(const DevScene &S, NodePtr
     }
 }
 
+// The walks of one BVH mesh for a whole wave at once, as a QUEUE of (ray, node) items.  In bvh_closest_postponed every lane
+// walks its own ray depth-first: the wave takes as many trips as its longest walk and a third of the lanes has work per
+// trip (mesh.json: 37 trips, 22 lanes).  Here the pending box tests of all rays of the wave wait in one last-in-first-out
+// queue in LDS - (owner lane, child reference, distance at which the ray enters the child's box) per item - and the wave
+// tests the top 64 items at a time: lane e fetches the owner's ray constants from the owner's registers (ds_bpermute) and
+// the owner's bound from its key, drops the item if its box now lies beyond the bound, else gathers the node, tests both
+// boxes and pushes the children that are hit, the nearer node last; children that are leaves go to the leaf list, which
+// grows down from the other end of the same area and is tested in dense batches as in bvh_closest_postponed (most recent
+// leaves first; a leaf whose box lies beyond its owner's bound by then is skipped).  A batch is dense whatever the rays'
+// depths, and a ray's subtrees are tested side by side: 22 rounds of dependent loads instead of 37.
+// Any order gives the same result: a key only ever takes the minimum over (distance, triangle index) of the triangles
+// tested, and a box is only skipped when it lies beyond the owner's key at the time (pruning on '>').
+// A ray's pending items are not bounded by the tree depth as a depth-first stack is; when a batch's pushes would not fit
+// they are dropped and the owners flagged, and flagged rays are walked again depth-first afterwards
+// (bvh_closest_postponed, from the root, with the bound the queue found: stacks and leaf list live where the queue was).
+struct WalkQueue {
+    uint32_t *redo;  // [2]: flags of the wave's lanes (+ 8 B of padding), then
+    uint2 *ent;      // [cap]: .x = owner lane | child << 6 (node index or leaf code), .y = bits of the entry distance;
+                     // box tests queue up from ent[0], leaves down from ent[cap - 1]
+    uint32_t cap;
+};
+constexpr uint32_t kWalkQueueHeader = 16;  // bytes in front of the entries
+
+template <class NodePtr>
+__device__ __forceinline__ void bvh_closest_queue(const DevScene &S, NodePtr nodes, const WalkQueue &Q, unsigned long long *keys,
+                                                  bool walk, vec3 o, vec3 d, int32_t root, float best_t, float &mt, int32_t &mid) {
+    // called by every active lane of the wave (the workers); `walk`: this lane's ray takes part.  keys: [64] of the wave
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t act = __builtin_amdgcn_ballot_w64(true);
+    const uint32_t n_act = (uint32_t)__builtin_popcountll(act);
+    const uint32_t my = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+    auto prefix = [](uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
+    auto count = [](uint64_t m) { return (uint32_t)__builtin_popcountll(m); };
+    // the key starts at "just beyond best_t, no triangle": the bound of a box test is always (key >> 32) + 1
+    if (walk) keys[lane] = ((unsigned long long)(__float_as_uint(best_t) - 1u) << 32) | 0xffffffffull;
+    if (my == 0u) Q.redo[0] = Q.redo[1] = 0u;
+    const float big = 1e18f;  // see bvh_closest
+    const vec3 inv = mk(__builtin_fmaxf(__builtin_fminf(1.0f / d.x, big), -big),
+                        __builtin_fmaxf(__builtin_fminf(1.0f / d.y, big), -big),
+                        __builtin_fmaxf(__builtin_fminf(1.0f / d.z, big), -big));
+    const vec3 oi = mk(o.x * inv.x, o.y * inv.y, o.z * inv.z);
+    uint32_t q_count, n_leaf;  // wave-uniform: box tests in ent[0, q_count), leaves in ent[cap - n_leaf, cap)
+    {
+        const uint64_t m_node = __builtin_amdgcn_ballot_w64(walk && root >= 0), m_leaf = __builtin_amdgcn_ballot_w64(walk && root < 0);
+        q_count = count(m_node);
+        n_leaf = count(m_leaf);
+        if (walk && root >= 0) Q.ent[prefix(m_node)] = make_uint2(lane | ((uint32_t)root << 6), 0u);
+        if (walk && root < 0) Q.ent[Q.cap - 1u - prefix(m_leaf)] = make_uint2(lane | ((uint32_t)~root << 6), 0u);
+    }
+    PT_WSTAT(S, 0, q_count + n_leaf);  // walks
+    PT_WSTAT(S, 10, 1);                // wave-walks
+    for (;;) {
+        if (q_count == 0u && n_leaf == 0u) break;
+        if (q_count != 0u) {
+            const uint32_t c = q_count < n_act ? q_count : n_act;
+            q_count -= c;
+            bool valid = my < c;
+            uint2 e = make_uint2(lane, 0u);
+            if (valid) e = Q.ent[q_count + my];
+            const uint32_t owner = e.x & 63u;
+            const int sel = (int)(owner << 2);
+            const float r_ivx = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(inv.x)));
+            const float r_ivy = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(inv.y)));
+            const float r_ivz = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(inv.z)));
+            const float r_oix = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(oi.x)));
+            const float r_oiy = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(oi.y)));
+            const float r_oiz = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(oi.z)));
+            const float bound = __uint_as_float((uint32_t)(load_key(&keys[owner]) >> 32) + 1u);
+            valid = valid && !(__uint_as_float(e.y) > bound);  // the owner has found something nearer since the item was pushed
+            PT_WSTAT(S, 1, 1);                                                               // batches of box tests
+            PT_WSTAT(S, 2, c);                                                               // items
+            PT_WSTAT(S, 3, __builtin_popcountll(__builtin_amdgcn_ballot_w64(valid)));        // ... still worth testing
+            bool h0 = false, h1 = false, first0 = true;
+            int32_t c0 = 0, c1 = 0;
+            f32x2 tin = splat2(0.0f);
+            if (valid) {
+                const BvhNode n = nodes[e.x >> 6];
+                hit_boxes(n, splat2(r_ivx), splat2(r_ivy), splat2(r_ivz), splat2(r_oix), splat2(r_oiy), splat2(r_oiz), bound, &h0, &h1,
+                          &tin);
+                first0 = tin[0] <= tin[1];
+                c0 = n.c[0];
+                c1 = n.c[1];
+            }
+            // children that are leaves -> leaf list; children that are nodes -> queue, the nearer of two on top
+            const bool l0 = h0 && c0 < 0, l1 = h1 && c1 < 0, n0 = h0 && c0 >= 0, n1 = h1 && c1 >= 0;
+            const bool two = n0 && n1, one = n0 || n1;
+            const uint64_t m_l0 = __builtin_amdgcn_ballot_w64(l0), m_l1 = __builtin_amdgcn_ballot_w64(l1);
+            const uint64_t m_far = __builtin_amdgcn_ballot_w64(two), m_near = __builtin_amdgcn_ballot_w64(one);
+            const uint32_t add_q = count(m_far) + count(m_near), add_l = count(m_l0) + count(m_l1);
+            if (q_count + n_leaf + add_q + add_l > Q.cap) {  // wave-uniform: no room - these rays are walked again afterwards
+                if (h0 || h1) atomicOr(&Q.redo[owner >> 5], 1u << (owner & 31u));
+                PT_WSTAT(S, 11, 1);
+            } else {
+                const bool near0 = two ? first0 : n0;  // which child is the (nearer) node pushed last
+                if (two) Q.ent[q_count + prefix(m_far)] = make_uint2(owner | ((uint32_t)(near0 ? c1 : c0) << 6), __float_as_uint(near0 ? tin[1] : tin[0]));
+                if (one) Q.ent[q_count + count(m_far) + prefix(m_near)] = make_uint2(owner | ((uint32_t)(near0 ? c0 : c1) << 6), __float_as_uint(near0 ? tin[0] : tin[1]));
+                q_count += add_q;
+                if (l0) Q.ent[Q.cap - 1u - (n_leaf + prefix(m_l0))] = make_uint2(owner | ((uint32_t)~c0 << 6), __float_as_uint(tin[0]));
+                if (l1) Q.ent[Q.cap - 1u - (n_leaf + count(m_l0) + prefix(m_l1))] = make_uint2(owner | ((uint32_t)~c1 << 6), __float_as_uint(tin[1]));
+                n_leaf += add_l;
+            }
+        }
+        // a dense batch of leaf tests whenever as many leaves wait as the wave has workers (before the next box tests: a hit
+        // tightens its owner's bound); what is left when the queue is empty.  The most recent leaves first.
+        while (n_leaf >= n_act || (q_count == 0u && n_leaf != 0u)) {
+            const uint32_t cnt = n_leaf < n_act ? n_leaf : n_act;
+            bool valid = my < cnt;
+            uint2 e = make_uint2(lane, 0u);
+            if (valid) e = Q.ent[Q.cap - n_leaf + my];
+            n_leaf -= cnt;
+            const uint32_t owner = e.x & 63u;
+            const int sel = (int)(owner << 2);
+            vec3 ro, rd;
+            ro.x = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(o.x)));
+            ro.y = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(o.y)));
+            ro.z = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(o.z)));
+            rd.x = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(d.x)));
+            rd.y = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(d.y)));
+            rd.z = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(d.z)));
+            const float bound = __uint_as_float((uint32_t)(load_key(&keys[owner]) >> 32) + 1u);
+            valid = valid && !(__uint_as_float(e.y) > bound);
+            PT_WSTAT(S, 5, 1);
+            PT_WSTAT(S, 6, cnt);
+            PT_WSTAT(S, 12, __builtin_popcountll(__builtin_amdgcn_ballot_w64(valid)));  // leaves still worth testing
+            const uint32_t code = e.x >> 6;
+            const uint32_t first = leaf_first(code), lc = valid ? leaf_count(code) : 0u;
+            for (uint32_t r = 0; r < kBvhLeafPairs; ++r) {
+                const bool has = r < lc;
+                if (__builtin_amdgcn_ballot_w64(has) == 0ull) break;
+                if (has) {
+                    const TriPairRec tr = S.tri_pairs[first + r];
+                    unsigned long long k2[2];
+                    float th[2];
+                    pair_test_keys(tr, ro, rd, k2, th);
+                    atomicMin(&keys[owner], k2[0]);
+                    atomicMin(&keys[owner], k2[1]);
+                }
+            }
+        }
+    }
+    if (walk) {
+        const unsigned long long key = load_key(&keys[lane]);
+        if ((uint32_t)key != 0xffffffffu) {
+            mt = __uint_as_float((uint32_t)(key >> 32) + 1u);
+            mid = (int32_t)(uint32_t)key;
+        }
+    }
+    // rays whose pushes were dropped: depth-first from the root, with the bound found so far
+    const uint32_t redo = __atomic_load_n(&Q.redo[lane >> 5], __ATOMIC_RELAXED);
+    const bool again = walk && ((redo >> (lane & 31u)) & 1u) != 0u;
+    if (__builtin_amdgcn_ballot_w64(again) != 0ull) {
+        if (again) {
+            StackDyn codec;
+            codec.narrow = true;
+            codec.c16.pair_base = S.bvh_pair_base;
+            LeafLds L;  // [stacks: bvh_stack x 64 x u16][leaf list: kLeafListCap x u32] in the queue's area
+            L.keys = keys;
+            L.list = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(Q.ent) + S.bvh_stack * 128u);
+            L.narrow_only = true;
+            float mt2 = __builtin_inff();
+            int32_t mid2 = -1;
+            bvh_closest_postponed(S, nodes, codec, reinterpret_cast<char *>(Q.ent) + lane * 2u, 128u, L, o, d, root,
+                                  __builtin_fminf(best_t, mt), mt2, mid2);
+            if (mid2 >= 0 && (mid < 0 || mt2 < mt || (mt2 == mt && (uint32_t)mid2 < (uint32_t)mid))) {
+                mt = mt2;
+                mid = mid2;
+            }
+        }
+    }
+}
+
 // LDS carve-up of the kernels that intersect: [BvhNode x n_bvh_nodes][u16 stack: kBvhStack x blockDim] when the
 // nodes are staged, else [u32 stack: kBvhStack x blockDim] alone (nodes read from global memory)
 __device__ __forceinline__ void stage_bvh(const DevScene &S, uint4 *lds) {
@@ -1181,8 +1352,8 @@ __device__ __forceinline__ bool bvh_wants(const DevScene &S, vec3 o, vec3 d, flo
 // 2. the walks of a parked ray: every BVH mesh in visiting order, exact gate first; the closest triangle of a mesh (the
 //    first in list order among equals: bvh_closest_postponed) enters the key with its rank - one integer minimum is
 //    intersect_scene's strict '<' over the whole visiting sequence (mod.rs:598,649), no tie needs a second look.
-__device__ __forceinline__ unsigned long long walk_deferred_keys(const DevScene &S, vec3 o, vec3 d, uint4 *lds,
-                                                                 unsigned long long key, const LeafLds *leaves) {
+__device__ __forceinline__ unsigned long long walk_deferred_keys(const DevScene &S, vec3 o, vec3 d, const WalkQueue &Q,
+                                                                 unsigned long long key, unsigned long long *wave_keys) {
     for (uint32_t q = 0; q < S.n_bvh_meshes; ++q) {
         const BvhMeshRec bm = ld_uniform(S.bvh_meshes + q);
         const vec3 op = mk(bm.cx, bm.cy, bm.cz) - o;
@@ -1193,7 +1364,7 @@ __device__ __forceinline__ unsigned long long walk_deferred_keys(const DevScene 
         if (__builtin_amdgcn_ballot_w64(pass) == 0ull) continue;
         float mt = __builtin_inff();
         int32_t mid = -1;
-        if (pass) bvh_walk(S, lds, o, d, bm.root, __uint_as_float((uint32_t)(key >> 32)), mt, mid, leaves);
+        bvh_closest_queue(S, S.bvh_nodes, Q, wave_keys, pass, o, d, bm.root, __uint_as_float((uint32_t)(key >> 32)), mt, mid);
         if (pass && mid >= 0) {
             const unsigned long long k2 = ((unsigned long long)__float_as_uint(mt) << 32) | S.tri_rank[mid];
             key = k2 < key ? k2 : key;

@@ -115,6 +115,8 @@ struct BvhBuilder {
         lo = mk(inf, inf, inf);
         hi = mk(-inf, -inf, -inf);
         depth_max = depth > depth_max ? depth : depth_max;
+        // (splitting such a run further where the surface-area heuristic would - a node step priced at 1, 2 or 4 triangle
+        // tests - loses on mesh.json: 15.8, 16.8, 17.5 against 17.8 G bounces/s; it is the node steps that cost)
         if (e - b <= 2u * kBvhLeafPairs) {  // leaf = up to kBvhLeafPairs consecutive TriPairRecs
             const size_t first = out.tri_pairs.size();
             for (size_t k0 = b; k0 < e; k0 += 2) {

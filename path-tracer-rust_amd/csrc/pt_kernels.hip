@@ -500,13 +500,18 @@ __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, R
 // (ray index + key, 12 B; the ray stays in the queue, a primary ray is generated again), and 64 parked rays at a time are
 // walked (leaves postponed: bvh_closest_postponed), their triangles folded into the key by rank, shaded and appended.
 // LDS of that form, between the per-wave candidate areas and the staged records:
-//   [traversal stacks: DevScene.bvh_stack x kBlock x u16|u32][per wave: park u32 idx x 128, u64 key x 128][per wave: LeafLds]
+//   [per wave: walk queue (pass_cand_queue_bytes)][per wave: park u32 idx x 128, u64 key x 128][per wave: u64 key x 64]
 constexpr uint32_t kCandParkCap = 128;  // 63 left over + 64 new at most
-__host__ __device__ inline size_t pass_cand_stack_bytes(const DevScene &S) {
-    return ((size_t)S.bvh_stack * kBlock * ((S.bvh_in_lds & 2u) ? sizeof(uint16_t) : sizeof(uint32_t)) + 15) & ~(size_t)15;
+// per wave: the walk queue (header + 8-byte entries: box tests from one end, leaves from the other), which is also where
+// the depth-first stacks (DevScene.bvh_stack entries x 64 lanes x u16) and the leaf list of the rare second walk live
+constexpr uint32_t kWalkQueueBytes = 2560;  // 320 entries
+__host__ __device__ inline size_t pass_cand_queue_bytes(const DevScene &S) {
+    const size_t again = (size_t)S.bvh_stack * 128u + kLeafListCap * 4u;
+    return kWalkQueueHeader + (((again > kWalkQueueBytes ? again : kWalkQueueBytes) + 15) & ~(size_t)15);
 }
+__host__ __device__ inline size_t pass_cand_stack_bytes(const DevScene &S) { return (size_t)(kBlock / 64u) * pass_cand_queue_bytes(S); }
 constexpr size_t kCandParkBytes = kCandParkCap * 12u;                  // per wave
-constexpr size_t kCandLeafBytes = 64u * 8u + kLeafListCap * 4u;        // per wave
+constexpr size_t kCandLeafBytes = 64u * 8u;                            // per wave: the walkers' keys
 __host__ __device__ inline size_t pass_cand_bvh_bytes(const DevScene &S) {
     return pass_cand_stack_bytes(S) + (size_t)(kBlock / 64u) * (kCandParkBytes + kCandLeafBytes);
 }
@@ -558,14 +563,17 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
     uint4 *const stacks = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(dyn_lds) + pass_lds_cand_offset(m, DEFER) + pass_lds_cand_bytes());
     uint32_t *p_idx = nullptr;
     unsigned long long *p_key = nullptr;
-    LeafLds leaves{};
+    unsigned long long *walk_keys = nullptr;
+    WalkQueue wq{};
     if (BVH) {
         char *wb = reinterpret_cast<char *>(stacks) + pass_cand_stack_bytes(S) + (size_t)(tid >> 6) * (kCandParkBytes + kCandLeafBytes);
         p_key = reinterpret_cast<unsigned long long *>(wb);
         p_idx = reinterpret_cast<uint32_t *>(wb + kCandParkCap * 8u);
-        leaves.keys = reinterpret_cast<unsigned long long *>(wb + kCandParkBytes);
-        leaves.list = reinterpret_cast<uint32_t *>(wb + kCandParkBytes + 64u * 8u);
-        leaves.narrow_only = true;  // (launch_pass: scenes with wider references run k_pass_bvh)
+        walk_keys = reinterpret_cast<unsigned long long *>(wb + kCandParkBytes);
+        char *qb = reinterpret_cast<char *>(stacks) + (size_t)(tid >> 6) * pass_cand_queue_bytes(S);
+        wq.redo = reinterpret_cast<uint32_t *>(qb);
+        wq.ent = reinterpret_cast<uint2 *>(qb + kWalkQueueHeader);
+        wq.cap = (uint32_t)((pass_cand_queue_bytes(S) - kWalkQueueHeader) / 8u);
     }
     const size_t base = (size_t)b * cap;
     ShadeParams P;
@@ -653,7 +661,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
             } else {
                 load_ray_slice(qin, i, in.o, in.d, in.thr, word);
             }
-            const unsigned long long key = walk_deferred_keys(S, in.o, in.d, stacks, p_key[e], &leaves);
+            const unsigned long long key = walk_deferred_keys(S, in.o, in.d, wq, p_key[e], walk_keys);
             const uint32_t rank = (uint32_t)key;
             if (rank != 0xffffffffu) {
                 in.pix = lds_pix[word_pix(word)];

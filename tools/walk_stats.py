@@ -27,17 +27,18 @@ out = (C.c_ulonglong * 16)()
 L.pt_debug_walk_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 assert L.pt_debug_walk_stats(ctx, out) == 0
 v = list(out)
-names = ["walks", "trips", "lanes_with_work", "node_steps", "-", "leaf_batches", "leaf_tests", "rays", "parked",
-         "scan_trips", "wave_walks"]
+names = ["walks", "box_batches", "items", "node_items", "-", "leaf_batches", "leaf_tests", "rays", "parked",
+         "scan_trips", "wave_walks", "overflows", "leaves_live"]
 for n, x in zip(names, v):
     print("%-16s %d" % (n, x))
 rays = float(v[7])
 print("bounces %d (stats rays %d)" % (st.ray_bounces, v[7]))
 print("parked / ray                %.3f" % (v[8] / rays))
-print("walks / ray                 %.3f  (lanes entering a mesh walk)" % (v[0] / rays))
-print("node steps / walk           %.2f" % (v[3] / max(v[0], 1)))
-print("trips / wave-walk           %.2f" % (v[1] / max(v[10], 1)))
-print("lanes with work / trip      %.2f of 64" % (v[2] / max(v[1], 1)))
-print("lanes on a node / trip      %.2f of 64" % (v[3] / max(v[1], 1)))
-print("leaf tests / walk           %.2f   per batch %.1f" % (v[6] / max(v[0], 1), v[6] / max(v[5], 1)))
-print("trips / ray                 %.3f wave-trips x 64 / rays" % (v[1] * 64 / rays))
+print("walks / ray                 %.3f  (rays entering a mesh walk)" % (v[0] / rays))
+print("node items / walk           %.2f" % (v[3] / max(v[0], 1)))
+print("box batches / wave-walk     %.2f" % (v[1] / max(v[10], 1)))
+print("items / box batch           %.2f of 64   (nodes %.2f)" % (v[2] / max(v[1], 1), v[3] / max(v[1], 1)))
+print("leaves / walk               %.2f   per leaf batch %.1f" % (v[6] / max(v[0], 1), v[6] / max(v[5], 1)))
+print("leaf batches / wave-walk    %.2f" % (v[5] / max(v[10], 1)))
+print("leaves still worth testing    %.3f of those popped" % (v[12] / max(v[6], 1)))
+print("batches with dropped pushes %d (%.4f per wave-walk)" % (v[11], v[11] / max(v[10], 1)))
