@@ -275,7 +275,7 @@ def main():
         # rank 0's launches of the dominant kernel (every rank runs the same kernel on its own rows)
         kernel = ctx.pass_kernel()
         rays, ms, launches = main_run["isect_rays"], main_run["isect_ms"], max(1, main_run["launches"])
-        if kernel in ("k_pass", "k_pass_cand"):
+        if kernel in ("k_pass", "k_pass_cand", "k_pass_cand_bvh"):
             # the primary rays are made in registers; every ray of depth >= 1 is appended once and read back once
             stored = rays - main_run["samples"]
         elif kernel == "k_pass_bvh":

@@ -64,6 +64,8 @@ struct Tuning {
     bool pass_bvh = true;      // PT_PASS_BVH=0: BVH scenes through the separate kernels
     bool bvh_lds = false;      // PT_BVH_LDS=1: stage BVH nodes in LDS (separate kernels only)
     bool cand_scan = true;     // PT_CAND_SCAN=0: k_pass scans every triangle per ray (the round-1 form) instead of candidates
+    uint32_t walk_queue_cap = 0;  // PT_WALK_QUEUE_CAP=n: the walk queue of k_pass_cand holds n entries (>= 128) instead of what its
+                                  // LDS area allows - small values exercise the depth-first second walk (tests)
     bool cand_bvh = true;      // PT_CAND_BVH=0: scenes with BVH meshes run k_pass_bvh (scan + parked walks) instead of
                                // the candidate scan with parked walks (k_pass_cand<.., BVH>)
     uint32_t leaf_quorum = 12; // PT_LEAF_QUORUM: lanes on a leaf that send a walking wave to the triangle code
@@ -81,6 +83,7 @@ static Tuning read_tuning() {
     t.bvh_lds = num("PT_BVH_LDS", 0) != 0;
     t.cand_scan = num("PT_CAND_SCAN", 1) != 0;
     t.cand_bvh = num("PT_CAND_BVH", 1) != 0;
+    t.walk_queue_cap = (uint32_t)num("PT_WALK_QUEUE_CAP", 0);
     t.leaf_quorum = (uint32_t)num("PT_LEAF_QUORUM", 12);
     const long long st = num("PT_STREAMS", 0);
     t.streams = st > 0 ? (uint64_t)st : 0;
@@ -282,7 +285,8 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
     // (scenes with a BVH stage its nodes into LDS once per workgroup: twice the work per stream; mesh.json 2048 streams
     // 7.3, 8192 7.6, 16384 7.0)
     // (candidate scan, four waves per SIMD: 12288 streams 35.8, 16384 35.4, 8192 32.2, 24576 33.7 G bounces/s)
-    const uint64_t per_stream = c->scene.n_bvh_nodes != 0u ? 4096u : (c->scene.cand_scan ? 2688u : 2048u);
+    // (candidate scan with walks, mesh.json: 20480 streams 19.3, 24576 19.4, 28672 19.8, 32768 19.5 G bounces/s)
+    const uint64_t per_stream = c->scene.n_bvh_nodes != 0u ? (c->scene.cand_scan ? 3584u : 4096u) : (c->scene.cand_scan ? 2688u : 2048u);
     uint64_t k_target = ((uint64_t)npix * spp_pass + per_stream - 1u) / per_stream;
     if (k_target < 2048u) k_target = 2048u;
     if (c->tune.streams) k_target = c->tune.streams;
@@ -713,6 +717,7 @@ int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uin
     c->cand_ok = fs.cand_ok;
     c->scene.cand_staged = 0u;
     c->scene.surf_staged = 0u;
+    c->scene.walk_queue_cap = c->tune.walk_queue_cap;
 #ifdef PT_WALK_STATS
     if (!c->scene.stats) {
         HIP_TRY(hipMalloc((void **)&c->scene.stats, 16 * sizeof(unsigned long long)));  // instrumented builds only: never freed
@@ -792,7 +797,7 @@ const char *pt_ctx_pass_kernel(const pt_ctx *c, uint32_t flags) {
     const bool bvh_ok = n_nodes == 0u || (!(c->scene.bvh_in_lds & 1u) && c->tune.pass_bvh);
     const bool one_kernel = bvh_ok && c->tune.pass_kernel && !(flags & PT_FLAG_SEPARATE_KERNELS);
     if (!one_kernel) return "k_intersect";
-    if (cand_scan_for(c, flags)) return "k_pass_cand";
+    if (cand_scan_for(c, flags)) return n_nodes != 0u ? "k_pass_cand_bvh" : "k_pass_cand";  // (k_pass_cand<.., BVH = true>)
     return n_nodes != 0u ? "k_pass_bvh" : "k_pass";
 }
 

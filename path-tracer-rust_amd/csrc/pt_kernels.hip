@@ -574,6 +574,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
         wq.redo = reinterpret_cast<uint32_t *>(qb);
         wq.ent = reinterpret_cast<uint2 *>(qb + kWalkQueueHeader);
         wq.cap = (uint32_t)((pass_cand_queue_bytes(S) - kWalkQueueHeader) / 8u);
+        if (S.walk_queue_cap >= 128u && S.walk_queue_cap < wq.cap) wq.cap = S.walk_queue_cap;
     }
     const size_t base = (size_t)b * cap;
     ShadeParams P;

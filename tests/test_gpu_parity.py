@@ -339,6 +339,47 @@ def test_full_size_mesh_bvh_vs_scan(gpu):
     assert 7.0 < res[0][1] / (w * h * spp) < 8.2  # 7.4-7.7 bounces per sample (survey probe / oracle)
 
 
+def test_mesh_walk_forms_agree(gpu):
+    """mesh.json through the three forms of the BVH walk - k_pass_cand_bvh (candidate scan, walks as a per-wave queue of
+    box tests), the same with a queue so small that most rays take the depth-first second walk, and k_pass_bvh (scan +
+    depth-first parked walks) - and through the reference-style full scan: the same frame, bit for bit, and the same
+    number of intersect_scene evaluations."""
+    L, _ = gpu
+    sc = ptlib.load_scene_py(ptlib.scene_path("mesh"))
+    w, h, spp = 320, 240, 16
+    res = {}
+    for name, env, flags in (("queue", {}, 0), ("tiny queue", {"PT_WALK_QUEUE_CAP": "128"}, 0),
+                             ("k_pass_bvh", {"PT_CAND_BVH": "0"}, 0), ("full scan", {}, ptlib.FLAG_NO_BVH)):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            ctx = C.c_void_p()
+            assert L.pt_ctx_create(0, C.byref(ctx)) == 0  # the tuning variables are read here
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        assert L.pt_ctx_set_scene(ctx, C.byref(sc.cam), sc.objs, sc.n_objs, sc.tris, sc.n_tris) == 0, L.pt_last_error()
+        kernel = L.pt_ctx_pass_kernel(ctx, flags).decode()
+        cfg = PtConfig(w, h, spp, 0, 3, 0, 0, 0, flags)
+        d = C.c_void_p()
+        assert L.pt_device_malloc(0, w * h * 12, C.byref(d)) == 0
+        st = PtStats()
+        assert L.pt_ctx_render(ctx, C.byref(cfg), d, None, None, None, None, C.byref(st)) == 0, L.pt_last_error()
+        img = np.empty((w * h, 3), np.float32)
+        assert L.pt_device_download(0, _np_f(img), d, img.nbytes) == 0
+        L.pt_device_free(0, d)
+        L.pt_ctx_destroy(ctx)
+        res[name] = (kernel, img, st.ray_bounces)
+    assert res["queue"][0] == "k_pass_cand_bvh" and res["tiny queue"][0] == "k_pass_cand_bvh"
+    assert res["k_pass_bvh"][0] == "k_pass_bvh" and res["full scan"][0] == "k_pass"
+    for name in ("tiny queue", "k_pass_bvh", "full scan"):
+        assert res[name][2] == res["queue"][2], name
+        assert np.array_equal(res[name][1], res["queue"][1]), name
+
+
 def test_render_multi_and_snapshot(gpu):
     """pt_render_multi with 1, 3 and 5 bands (all on this box's one GPU) == pt_render, bit for bit; the progress
     callback can pull partial frames with pt_ctx_snapshot and the last one (all spp) equals the final image."""

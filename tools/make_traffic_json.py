@@ -34,16 +34,19 @@ NOTE = ("insts_per_ray = SQ_INSTS_VALU x 64 / rays (dynamic); busy_frac = SQ_ACT
         "and the no-packed-instruction A/B of DESIGN section 4); avg_cost = sum(count x cost) / count")
 ASM = os.path.join(ROOT, "path-tracer-rust_amd", "pt_kernels.s")
 # kernel name in the profile -> symbol fragment in the listing (most specific first)
-KERNELS = [("k_pass_cand", "k_pass_candILb1ELb1"), ("k_pass_bvh", "k_pass_bvhE"), ("k_pass<", "k_passILb1"),
-           ("k_intersect", "k_intersectILb0"), ("k_mega", "k_megaILb0")]
+# (k_pass_cand<STAGED, DEFER, BVH>: "true, true, false" is the bench scene's, "true, false, true" mesh.json's: pt_ctx_pass_kernel
+# calls the latter k_pass_cand_bvh, and bench.py looks its traffic up under that name)
+KERNELS = [("k_pass_cand<true, false, true>", "k_pass_candILb1ELb0ELb1", "k_pass_cand_bvh"),
+           ("k_pass_cand<true, true, false>", "k_pass_candILb1ELb1ELb0", "k_pass_cand"), ("k_pass_bvh", "k_pass_bvhE", None),
+           ("k_pass<", "k_passILb1", None), ("k_intersect", "k_intersectILb0", None), ("k_mega", "k_megaILb0", None)]
 done = {}
-for kname, sym in KERNELS:
+for kname, sym, label in KERNELS:
     sq = kernel(out["sq"], kname)
     if sq is None:
         continue
     fetch = kernel(out["fetch"], kname)["FETCH_SIZE"] * 1024.0  # counter is in KiB
     write = kernel(out["write"], kname)["WRITE_SIZE"] * 1024.0
-    clean = kname.rstrip("<")
+    clean = label or kname.rstrip("<")
     static = isa_mix.mix(ASM, sym) if os.path.exists(ASM) else None
     tr = {
         "kernel": clean,
