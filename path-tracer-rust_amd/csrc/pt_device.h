@@ -89,10 +89,12 @@ constexpr uint32_t kNoTri = 0x7fffffffu;
 constexpr uint32_t kBvhStack = 24;          // per-lane traversal stack entries (LDS; u16 each when nodes are staged)
 constexpr uint32_t kBvhMinTris = 16;        // meshes with fewer triangles are scanned linearly
 // A BVH leaf is a run of up to kBvhLeafPairs consecutive pair records.  A leaf reference is ~(first record << kBvhLeafBits | count - 1).
-// Dense leaf batches make a pair test cheaper than a node step (k_pass_bvh: about 1.7 against 2.3 wave-instructions per
-// lane-unit of work), so the last two levels of the tree are better spent as tests: mesh.json 14.6 -> see DESIGN.
+// Dense leaf batches make a pair test cheaper than a depth-first node step, so the last levels of the tree are better
+// spent as tests (k_pass_bvh, depth-first walks: 1 record per leaf 14.4, 2: 15.4, 4: 15.5, 8: 15.2 G bounces/s on
+// mesh.json).  With the box tests dense too (k_pass_cand's walk queue) the balance moves back a little:
+// 1: 19.5, 2: 20.0, 3: 20.2, 4: 19.8.
 #ifndef PT_BVH_LEAF_PAIRS
-#define PT_BVH_LEAF_PAIRS 4
+#define PT_BVH_LEAF_PAIRS 3
 #endif
 constexpr uint32_t kBvhLeafPairs = PT_BVH_LEAF_PAIRS;
 constexpr uint32_t kBvhLeafBits = kBvhLeafPairs <= 2 ? 1 : (kBvhLeafPairs <= 4 ? 2 : (kBvhLeafPairs <= 8 ? 3 : 4));
@@ -1383,10 +1385,14 @@ __device__ __forceinline__ unsigned long long walk_deferred_keys(const DevScene 
         float mt = __builtin_inff();
         int32_t mid = -1;
         bvh_closest_queue(S, S.bvh_nodes, Q, wave_keys, pass, o, d, bm.root, __uint_as_float((uint32_t)(key >> 32)), mt, mid);
+        bool won = false;
         if (pass && mid >= 0) {
             const unsigned long long k2 = ((unsigned long long)__float_as_uint(mt) << 32) | S.tri_rank[mid];
+            won = k2 < key;
             key = k2 < key ? k2 : key;
         }
+        PT_WSTAT(S, 13, __builtin_popcountll(__builtin_amdgcn_ballot_w64(won)));  // walks that found the ray's hit
+        (void)won;
     }
     return key;
 }
