@@ -285,8 +285,8 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
     // (scenes with a BVH stage its nodes into LDS once per workgroup: twice the work per stream; mesh.json 2048 streams
     // 7.3, 8192 7.6, 16384 7.0)
     // (candidate scan, four waves per SIMD: 12288 streams 35.8, 16384 35.4, 8192 32.2, 24576 33.7 G bounces/s)
-    // (candidate scan with walks, mesh.json: 20480 streams 19.3, 24576 19.4, 28672 19.8, 32768 19.5 G bounces/s)
-    const uint64_t per_stream = c->scene.n_bvh_nodes != 0u ? (c->scene.cand_scan ? 3584u : 4096u) : (c->scene.cand_scan ? 2688u : 2048u);
+    // (candidate scan with walks, mesh.json: 24576 streams 19.8, 26624 20.5, 28672 20.1, 30720 20.3, 32768 19.9 G bounces/s)
+    const uint64_t per_stream = c->scene.n_bvh_nodes != 0u ? (c->scene.cand_scan ? 3840u : 4096u) : (c->scene.cand_scan ? 2688u : 2048u);
     uint64_t k_target = ((uint64_t)npix * spp_pass + per_stream - 1u) / per_stream;
     if (k_target < 2048u) k_target = 2048u;
     if (c->tune.streams) k_target = c->tune.streams;
