@@ -182,9 +182,8 @@ int pt_ctx_set_profiling(pt_ctx *ctx, int enabled);
 /* Name of the kernel the wavefront backend launches for this context's scene with these pt_config.flags - the one
  * pt_stats.intersect_launches / ms_intersect describe: "k_pass_cand" (one launch per pass, candidate scan: scenes
  * without BVH meshes), "k_pass_cand_bvh" (the same kernel's form for scenes with BVH meshes: candidate scan + parked
- * walks), "k_pass" (every triangle tested per ray), "k_pass_bvh" (scan + parked walks; BVHs whose child references
- * need more than 16 bits, or PT_CAND_BVH=0), or "k_intersect" (separate kernels).  For profilers and bench.py; NULL
- * without a scene. */
+ * walks), "k_pass" (every triangle tested per ray), "k_pass_bvh" (scan + depth-first parked walks: PT_CAND_BVH=0),
+ * or "k_intersect" (separate kernels).  For profilers and bench.py; NULL without a scene. */
 const char *pt_ctx_pass_kernel(const pt_ctx *ctx, uint32_t flags);
 
 /* Single-ray queries through the same device intersection code (a6): the callers are object

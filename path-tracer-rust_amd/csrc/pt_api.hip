@@ -253,11 +253,10 @@ hipEvent_t get_event(pt_ctx *c, size_t i) {
 }
 
 // does a frame with these flags run the candidate scan (k_pass_cand)?  Scenes with BVH meshes: with parked walks, unless
-// their nodes are staged in LDS (PT_BVH_LDS=1), their child references need more than 16 bits (32 768 nodes or leaves)
-// or PT_CAND_BVH=0 asks for k_pass_bvh.
+// their nodes are staged in LDS (PT_BVH_LDS=1) or PT_CAND_BVH=0 asks for k_pass_bvh.
 static uint32_t cand_scan_for(const pt_ctx *c, uint32_t flags) {
     if (!c->tune.cand_scan || !c->cand_ok || (flags & PT_FLAG_NO_BVH)) return 0u;
-    if (c->n_bvh_nodes != 0u && (!c->tune.cand_bvh || (c->scene.bvh_in_lds & 3u) != 2u)) return 0u;  // (16-bit child references)
+    if (c->n_bvh_nodes != 0u && (!c->tune.cand_bvh || (c->scene.bvh_in_lds & 1u))) return 0u;
     return 1u;
 }
 

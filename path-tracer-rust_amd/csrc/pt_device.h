@@ -610,7 +610,6 @@ __device__ __forceinline__ unsigned long long load_key(const unsigned long long 
 struct LeafLds {
     unsigned long long *keys;  // [64] of this wave
     uint32_t *list;            // [kLeafListCap] of this wave: lane | leaf code << 6 (leaf_first / leaf_count)
-    bool narrow_only;          // the caller only runs scenes whose child references fit 16 bits (k_pass_cand)
 };
 constexpr uint32_t kLeafListCap = 128u;  // < 64 left over + at most 64 leaves appended by one step
 
@@ -887,15 +886,15 @@ __device__ __forceinline__ void bvh_closest_queue(const DevScene &S, NodePtr nod
     if (__builtin_amdgcn_ballot_w64(again) != 0ull) {
         if (again) {
             StackDyn codec;
-            codec.narrow = true;
+            codec.narrow = (S.bvh_in_lds & 2u) != 0u;
             codec.c16.pair_base = S.bvh_pair_base;
-            LeafLds L;  // [stacks: bvh_stack x 64 x u16][leaf list: kLeafListCap x u32] in the queue's area
+            const uint32_t eb = codec.entry_bytes();
+            LeafLds L;  // [stacks: bvh_stack x 64 x u16|u32][leaf list: kLeafListCap x u32] in the queue's area
             L.keys = keys;
-            L.list = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(Q.ent) + S.bvh_stack * 128u);
-            L.narrow_only = true;
+            L.list = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(Q.ent) + S.bvh_stack * 64u * eb);
             float mt2 = __builtin_inff();
             int32_t mid2 = -1;
-            bvh_closest_postponed(S, nodes, codec, reinterpret_cast<char *>(Q.ent) + lane * 2u, 128u, L, o, d, root,
+            bvh_closest_postponed(S, nodes, codec, reinterpret_cast<char *>(Q.ent) + lane * eb, 64u * eb, L, o, d, root,
                                   __builtin_fminf(best_t, mt), mt2, mid2);
             if (mid2 >= 0 && (mid < 0 || mt2 < mt || (mt2 == mt && (uint32_t)mid2 < (uint32_t)mid))) {
                 mt = mt2;
@@ -927,7 +926,7 @@ __device__ __forceinline__ void bvh_walk(const DevScene &S, uint4 *lds, vec3 o, 
     uint4 *const stacks = (S.bvh_in_lds & 1u) ? lds + S.n_bvh_nodes * 4u : lds;
     if (leaves) {  // k_pass_bvh, k_pass_cand: nodes in global memory, leaves postponed
         StackDyn codec;
-        codec.narrow = leaves->narrow_only || (S.bvh_in_lds & 2u) != 0u;  // (a literal `true` folds the other width away)
+        codec.narrow = (S.bvh_in_lds & 2u) != 0u;
         codec.c16.pair_base = S.bvh_pair_base;
         const uint32_t eb = codec.entry_bytes();
         bvh_closest_postponed(S, S.bvh_nodes, codec, reinterpret_cast<char *>(stacks) + threadIdx.x * eb, blockDim.x * eb, *leaves,

@@ -503,10 +503,11 @@ __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, R
 //   [per wave: walk queue (pass_cand_queue_bytes)][per wave: park u32 idx x 128, u64 key x 128][per wave: u64 key x 64]
 constexpr uint32_t kCandParkCap = 128;  // 63 left over + 64 new at most
 // per wave: the walk queue (header + 8-byte entries: box tests from one end, leaves from the other), which is also where
-// the depth-first stacks (DevScene.bvh_stack entries x 64 lanes x u16) and the leaf list of the rare second walk live
+// the depth-first stacks (DevScene.bvh_stack entries x 64 lanes x u16, or u32 when a tree has 32 768 nodes or leaves) and
+// the leaf list of the rare second walk live
 constexpr uint32_t kWalkQueueBytes = 2560;  // 320 entries
 __host__ __device__ inline size_t pass_cand_queue_bytes(const DevScene &S) {
-    const size_t again = (size_t)S.bvh_stack * 128u + kLeafListCap * 4u;
+    const size_t again = (size_t)S.bvh_stack * 64u * ((S.bvh_in_lds & 2u) ? 2u : 4u) + kLeafListCap * 4u;
     return kWalkQueueHeader + (((again > kWalkQueueBytes ? again : kWalkQueueBytes) + 15) & ~(size_t)15);
 }
 __host__ __device__ inline size_t pass_cand_stack_bytes(const DevScene &S) { return (size_t)(kBlock / 64u) * pass_cand_queue_bytes(S); }
@@ -870,7 +871,6 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_bvh(DevScene S, FrameParams 
         char *lbase = reinterpret_cast<char *>(dyn_lds) + pass_bvh_leaf_offset(S, m) + (size_t)(tid >> 6) * (64u * 8u + kLeafListCap * 4u);
         leaves.keys = reinterpret_cast<unsigned long long *>(lbase);
         leaves.list = reinterpret_cast<uint32_t *>(lbase + 64u * 8u);
-        leaves.narrow_only = false;
     }
     const size_t base = (size_t)b * cap;
     ShadeParams P;

@@ -380,6 +380,86 @@ def test_mesh_walk_forms_agree(gpu):
         assert np.array_equal(res[name][1], res["queue"][1]), name
 
 
+def test_wide_bvh_through_the_walk_queue(gpu):
+    """A mesh of 36 480 triangles: its BVH has more leaves than 16-bit child references can number, so the depth-first
+    walkers keep u32 stacks.  The walk queue (k_pass_cand_bvh), the same with a queue so small that the depth-first
+    second walk (u32 stacks in the queue's LDS) does most of the work, and k_pass_bvh give the same frame, bit for bit;
+    single rays agree with the oracle's linear scan."""
+    L, _ = gpu
+    O = ptlib.oracle()
+    steps = 96
+    tris = []
+    for i in range(steps):
+        t1, t2 = np.pi * i / steps, np.pi * (i + 1) / steps
+        for j in range(2 * steps):
+            p1, p2 = np.pi * j / steps, np.pi * (j + 1) / steps
+            r = lambda t, p: 1.0 + 0.04 * np.sin(9 * t) * np.cos(7 * p)
+            P = lambda t, p: (r(t, p) * np.sin(t) * np.cos(p), r(t, p) * np.cos(t), r(t, p) * np.sin(t) * np.sin(p))
+            a, b, c, d = P(t1, p1), P(t2, p1), P(t2, p2), P(t1, p2)
+            if i == 0:
+                tris.append((a, c, d))
+            elif i + 1 == steps:
+                tris.append((a, b, c))
+            else:
+                tris.append((a, b, d))
+                tris.append((b, c, d))
+    tris = [ptlib.make_tri(*t) for t in tris]
+    assert len(tris) == 36480
+    cam = ptlib.make_camera((0, 0.3, 4.5), (0, -0.05, -1))
+    objs = [ptlib.make_sphere((0, 0, 0), 12.0, (0.7, 0.7, 0.7), (0.5, 0.5, 0.5), "Diffuse"),
+            ptlib.make_sphere((1.6, -0.4, 0.8), 0.5, (0.9, 0.9, 0.9), (0, 0, 0), "Refract"),
+            ptlib.make_mesh((-0.3, 0, 0), (0.8, 0.5, 0.3), (0, 0, 0), "Diffuse", 0, len(tris), (0, 0, 0), 1.05)]
+    sc = ptlib.Scene("wide", cam, objs, tris)
+    w, h, spp = 160, 120, 8
+    res = {}
+    for name, env in (("queue", {}), ("tiny queue", {"PT_WALK_QUEUE_CAP": "128"}), ("k_pass_bvh", {"PT_CAND_BVH": "0"})):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            ctx = C.c_void_p()
+            assert L.pt_ctx_create(0, C.byref(ctx)) == 0
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        assert L.pt_ctx_set_scene(ctx, C.byref(sc.cam), sc.objs, sc.n_objs, sc.tris, sc.n_tris) == 0, L.pt_last_error()
+        kernel = L.pt_ctx_pass_kernel(ctx, 0).decode()
+        cfg = PtConfig(w, h, spp, 0, 5, 0, 0, 0, 0)
+        d = C.c_void_p()
+        assert L.pt_device_malloc(0, w * h * 12, C.byref(d)) == 0
+        st = PtStats()
+        assert L.pt_ctx_render(ctx, C.byref(cfg), d, None, None, None, None, C.byref(st)) == 0, L.pt_last_error()
+        img = np.empty((w * h, 3), np.float32)
+        assert L.pt_device_download(0, _np_f(img), d, img.nbytes) == 0
+        L.pt_device_free(0, d)
+        if name == "queue":  # single rays against the oracle's scan (k_query: depth-first, u32 stacks)
+            rng = np.random.default_rng(11)
+            n = 4000
+            o = rng.uniform(-2.5, 2.5, size=(n, 3)).astype(np.float32)
+            dd = rng.normal(size=(n, 3)).astype(np.float32) * 0.7 - o
+            dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+            o, dd = np.ascontiguousarray(o), np.ascontiguousarray(dd.astype(np.float32))
+            out = []
+            ps = sc.pto()
+            for fn, handle in ((L.pt_ctx_intersect, ctx), (O.pto_intersect_batch, C.byref(ps))):
+                t, oid, tid = np.zeros(n, np.float32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+                assert fn(handle, _np_f(o), _np_f(dd), n, _np_f(t), oid.ctypes.data_as(ptlib.i32p),
+                          tid.ctypes.data_as(ptlib.i32p), None, None) == 0
+                out.append((t, oid, tid))
+            assert (out[1][1] == 2).mean() > 0.2
+            assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+            assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+        L.pt_ctx_destroy(ctx)
+        res[name] = (kernel, img, st.ray_bounces)
+    assert res["queue"][0] == "k_pass_cand_bvh" and res["k_pass_bvh"][0] == "k_pass_bvh"
+    assert res["queue"][1].max() > 0.0
+    for name in ("tiny queue", "k_pass_bvh"):
+        assert res[name][2] == res["queue"][2], name
+        assert np.array_equal(res[name][1], res["queue"][1]), name
+
+
 def test_render_multi_and_snapshot(gpu):
     """pt_render_multi with 1, 3 and 5 bands (all on this box's one GPU) == pt_render, bit for bit; the progress
     callback can pull partial frames with pt_ctx_snapshot and the last one (all spp) equals the final image."""
