@@ -498,7 +498,8 @@ __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, R
 // BVH = true (scenes with BVH meshes): when a ray is finished - its key holds the best of the spheres and of the candidate
 // records - bvh_wants decides whether it has to walk a BVH mesh; such a ray is not shaded but PARKED per wave in LDS
 // (ray index + key, 12 B; the ray stays in the queue, a primary ray is generated again), and 64 parked rays at a time are
-// walked (leaves postponed: bvh_closest_postponed), their triangles folded into the key by rank, shaded and appended.
+// walked (bvh_closest_queue: the wave's pending box tests as one queue), the closest triangle folded into the key by rank,
+// shaded and appended.
 // LDS of that form, between the per-wave candidate areas and the staged records:
 //   [per wave: walk queue (pass_cand_queue_bytes)][per wave: park u32 idx x 128, u64 key x 128][per wave: u64 key x 64]
 constexpr uint32_t kCandParkCap = 128;  // 63 left over + 64 new at most
@@ -510,13 +511,13 @@ __host__ __device__ inline size_t pass_cand_queue_bytes(const DevScene &S) {
     const size_t again = (size_t)S.bvh_stack * 64u * ((S.bvh_in_lds & 2u) ? 2u : 4u) + kLeafListCap * 4u;
     return kWalkQueueHeader + (((again > kWalkQueueBytes ? again : kWalkQueueBytes) + 15) & ~(size_t)15);
 }
-__host__ __device__ inline size_t pass_cand_stack_bytes(const DevScene &S) { return (size_t)(kBlock / 64u) * pass_cand_queue_bytes(S); }
+__host__ __device__ inline size_t pass_cand_queues_bytes(const DevScene &S) { return (size_t)(kBlock / 64u) * pass_cand_queue_bytes(S); }
 constexpr size_t kCandParkBytes = kCandParkCap * 12u;                  // per wave
-constexpr size_t kCandLeafBytes = 64u * 8u;                            // per wave: the walkers' keys
+constexpr size_t kCandWalkKeyBytes = 64u * 8u;                         // per wave: the walkers' keys
 __host__ __device__ inline size_t pass_cand_bvh_bytes(const DevScene &S) {
-    return pass_cand_stack_bytes(S) + (size_t)(kBlock / 64u) * (kCandParkBytes + kCandLeafBytes);
+    return pass_cand_queues_bytes(S) + (size_t)(kBlock / 64u) * (kCandParkBytes + kCandWalkKeyBytes);
 }
-static_assert(kCandParkBytes % 16u == 0u && kCandLeafBytes % 16u == 0u, "per-wave areas stay 16-byte aligned");
+static_assert(kCandParkBytes % 16u == 0u && kCandWalkKeyBytes % 16u == 0u, "per-wave areas stay 16-byte aligned");
 
 // (The workgroup's own copy of the nodes in LDS, in front of the stacks, was tried: mesh.json's 141 nodes are 9 KB, which
 // leaves room for three workgroups per CU instead of four - 16.1 against 17.8 G bounces/s.)
@@ -560,18 +561,18 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
             }
         }
     }
-    // BVH: traversal stacks of the workgroup, then this wave's parking area and leaf list
-    uint4 *const stacks = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(dyn_lds) + pass_lds_cand_offset(m, DEFER) + pass_lds_cand_bytes());
+    // BVH: the waves' walk queues, then this wave's parking area and walk keys
+    char *const walk_lds = (reinterpret_cast<char *>(dyn_lds) + pass_lds_cand_offset(m, DEFER) + pass_lds_cand_bytes());
     uint32_t *p_idx = nullptr;
     unsigned long long *p_key = nullptr;
     unsigned long long *walk_keys = nullptr;
     WalkQueue wq{};
     if (BVH) {
-        char *wb = reinterpret_cast<char *>(stacks) + pass_cand_stack_bytes(S) + (size_t)(tid >> 6) * (kCandParkBytes + kCandLeafBytes);
+        char *wb = walk_lds + pass_cand_queues_bytes(S) + (size_t)(tid >> 6) * (kCandParkBytes + kCandWalkKeyBytes);
         p_key = reinterpret_cast<unsigned long long *>(wb);
         p_idx = reinterpret_cast<uint32_t *>(wb + kCandParkCap * 8u);
         walk_keys = reinterpret_cast<unsigned long long *>(wb + kCandParkBytes);
-        char *qb = reinterpret_cast<char *>(stacks) + (size_t)(tid >> 6) * pass_cand_queue_bytes(S);
+        char *qb = walk_lds + (size_t)(tid >> 6) * pass_cand_queue_bytes(S);
         wq.redo = reinterpret_cast<uint32_t *>(qb);
         wq.ent = reinterpret_cast<uint2 *>(qb + kWalkQueueHeader);
         wq.cap = (uint32_t)((pass_cand_queue_bytes(S) - kWalkQueueHeader) / 8u);
@@ -1357,7 +1358,7 @@ void launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const FrameParam
         const size_t walk = bvh ? pass_cand_bvh_bytes(S2) : 0u;
         const size_t rec_cand = (size_t)S.n_cand_pairs * sizeof(CandPairRec);
         const size_t rec_surf = (size_t)(S.n_objs + S.n_tris) * sizeof(SurfRec);
-        // glass deferral: not with walks (their stacks take its place; a walked ray is shaded in place anyway)
+        // glass deferral: not with walks (their queues take its place in LDS; a walked ray is shaded in place anyway)
         const bool defer = !bvh && pass_lds_cand_offset(m, true) + pass_lds_cand_bytes() <= budget;
         const size_t before = pass_lds_cand_offset(m, defer) + pass_lds_cand_bytes() + walk;
         S2.surf_staged = before + rec_cand + rec_surf <= budget ? 1u : 0u;
