@@ -817,6 +817,9 @@ __device__ __forceinline__ void bvh_closest_queue(const DevScene &S, NodePtr nod
                 c1 = n.c[1];
             }
             // children that are leaves -> leaf list; children that are nodes -> queue, the nearer of two on top
+            // (sending the farther of two hit children, when it is a leaf, through the queue once more - to be dropped if
+            // the nearer subtree has found something in front of it by then - does not pay: the nearer leaf has rarely
+            // been tested when the item comes up again; 5.12 instead of 5.18 leaves per walk, 20.3 instead of 18.2 batches)
             const bool l0 = h0 && c0 < 0, l1 = h1 && c1 < 0, n0 = h0 && c0 >= 0, n1 = h1 && c1 >= 0;
             const bool two = n0 && n1, one = n0 || n1;
             const uint64_t m_l0 = __builtin_amdgcn_ballot_w64(l0), m_l1 = __builtin_amdgcn_ballot_w64(l1);
