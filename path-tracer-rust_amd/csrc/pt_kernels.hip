@@ -1365,8 +1365,14 @@ void launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const FrameParam
         // (without walks the records are staged whole or not at all; with walks the candidate records alone may be)
         const bool staged = bvh ? (S2.surf_staged || before + rec_cand <= budget + 8u * 1024u) : S2.surf_staged != 0u;
         const size_t lds = before + (staged ? rec_cand + (S2.surf_staged ? rec_surf : 0u) : 0u);
+        // (more than 64 KB of dynamic LDS - wide deep trees with hundreds of pixels per stream - has to be asked for)
 #define PT_LAUNCH_CAND(ST, DF, BV)                                                                                     \
-    hipLaunchKernelGGL((k_pass_cand<ST, DF, BV>), dim3(K), dim3(kBlock), lds, st, S2, F, q0, q1, cap, s0, s_here, m, acc, blk_rays, flags)
+    do {                                                                                                               \
+        if (lds > 64u * 1024u)                                                                                         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pass_cand<ST, DF, BV>),                         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
+        hipLaunchKernelGGL((k_pass_cand<ST, DF, BV>), dim3(K), dim3(kBlock), lds, st, S2, F, q0, q1, cap, s0, s_here, m, acc, blk_rays, flags); \
+    } while (0)
         if (bvh && staged)
             PT_LAUNCH_CAND(true, false, true);
         else if (bvh)

@@ -1,6 +1,6 @@
 """A scene with one large mesh (a bumpy sphere of 2 x n x 2n triangles inside an emissive sphere, next to a glass ball):
 frame time through the walk queue (k_pass_cand_bvh) and through k_pass_bvh (PT_CAND_BVH=0), images compared.
-python tools/bigmesh_probe.py [n=256] [spp=64]"""
+python tools/bigmesh_probe.py [n=256] [spp=64] [width=1024] [height=768] [rays_per_pass=0: the library's default]"""
 import ctypes as C
 import os
 import sys
@@ -16,7 +16,9 @@ if os.environ.get("PT_LIB"):
 L = ptlib.product()
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-W, H = 1024, 768
+W = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+H = int(sys.argv[4]) if len(sys.argv) > 4 else 768
+RPP = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 t = np.linspace(0, np.pi, steps + 1)[:, None]
 p = np.linspace(0, 2 * np.pi, 2 * steps + 1)[None, :]
 r = 1.0 + 0.04 * np.sin(9 * t) * np.cos(7 * p)
@@ -40,7 +42,7 @@ for env in ({}, {"PT_CAND_BVH": "0"}):
     t0 = time.perf_counter()
     assert L.pt_ctx_set_scene(ctx, C.byref(sc.cam), sc.objs, sc.n_objs, sc.tris, sc.n_tris) == 0, L.pt_last_error()
     t_scene = time.perf_counter() - t0
-    cfg = PtConfig(W, H, spp, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0)
+    cfg = PtConfig(W, H, spp, 0, 1, 0, 0, RPP, 0, 0, 0, 0, 0)
     dev = C.c_void_p()
     assert L.pt_device_malloc(0, W * H * 12, C.byref(dev)) == 0
     st = PtStats()
