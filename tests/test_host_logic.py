@@ -88,3 +88,83 @@ def test_rust_shim_mirrors_the_header():
         r_val = int(re.search(r"pub const %s: i32 = (-?\d+);" % name, rust).group(1))
         assert c_val == r_val
     assert len(re.findall(r"pub fn pt_render\(", rust)) == 1 and "pub fn flatten(" in rust
+
+FLATTEN_SRC = r"""
+#include <cstdio>
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "ptrace.h"
+#include "pt_host.h"
+using namespace pt;
+static int depth_of(const host::FlatScene &fs, int32_t ref, std::vector<int> &leaf_hits, uint32_t pair_lo, uint32_t pair_hi, bool &ok) {
+    if (ref < 0) {
+        const uint32_t code = (uint32_t)~ref, first = leaf_first(code), cnt = leaf_count(code);
+        if (cnt < 1 || cnt > kBvhLeafPairs || first < pair_lo || first + cnt > pair_hi) ok = false;
+        for (uint32_t r = 0; r < cnt && ok; ++r)
+            for (int hf = 0; hf < 2; ++hf)
+                if (fs.tri_pairs[first + r].id[hf] != kNoTri) leaf_hits[fs.tri_pairs[first + r].id[hf]]++;
+        return 0;
+    }
+    const BvhNode &n = fs.bvh_nodes[ref];
+    const int a = depth_of(fs, n.c[0], leaf_hits, pair_lo, pair_hi, ok), b = depth_of(fs, n.c[1], leaf_hits, pair_lo, pair_hi, ok);
+    return 1 + (a > b ? a : b);
+}
+int main(int argc, char **argv) {
+    pt_scene *sc = nullptr;
+    if (pt_scene_load(argv[1], argv[2], &sc) != 0) { printf("FAIL load %s\n", pt_last_error()); return 1; }
+    uint32_t n_objs, n_tris;
+    const pt_object *objs = pt_scene_objects(sc, &n_objs);
+    const pt_triangle *tris = pt_scene_triangles(sc, &n_tris);
+    host::FlatScene fs;
+    std::string err;
+    if (!host::flatten_scene(*pt_scene_camera(sc), objs, n_objs, tris, n_tris, fs, err)) { printf("FAIL flatten %s\n", err.c_str()); return 1; }
+    // ranks: rank_id and tri_rank are inverse on the triangles; objects from the last to the first
+    if (fs.tri_rank.size() < n_tris) { printf("FAIL tri_rank size\n"); return 1; }
+    for (uint32_t k = 0; k < n_tris; ++k)
+        if (fs.rank_id[fs.tri_rank[k]] != n_objs + k) { printf("FAIL tri_rank %u\n", k); return 1; }
+    // the BVH mesh list: exactly the objects with a BVH, in visiting order
+    size_t q = 0;
+    uint32_t deepest = 0;
+    for (uint32_t v = 0; v < n_objs; ++v) {
+        const ObjRec &r = fs.objs[n_objs - 1u - v];
+        if (r.kind != kKindMesh || r.bvh_root == kNoBvh) continue;
+        if (q >= fs.bvh_meshes.size() || fs.bvh_meshes[q].root != r.bvh_root || fs.bvh_meshes[q].rr != r.rr ||
+            fs.bvh_meshes[q].cx != r.cx) { printf("FAIL bvh_meshes %zu\n", q); return 1; }
+        ++q;
+        // the tree: every triangle of the mesh in exactly one leaf, leaves within the mesh's records, depth within the stack
+        std::vector<int> hits(n_tris, 0);
+        bool ok = true;
+        const int d = depth_of(fs, r.bvh_root, hits, r.pair_begin, r.pair_begin + r.pair_count, ok);
+        if (!ok) { printf("FAIL leaf\n"); return 1; }
+        for (uint32_t k = 0; k < n_tris; ++k)
+            if (hits[k] != ((k >= r.tri_begin && k < r.tri_begin + r.tri_count) ? 1 : 0)) { printf("FAIL cover %u\n", k); return 1; }
+        deepest = (uint32_t)d > deepest ? (uint32_t)d : deepest;
+    }
+    if (q != fs.bvh_meshes.size()) { printf("FAIL bvh_meshes count\n"); return 1; }
+    if (q != 0 && (fs.bvh_stack < deepest + 1u || fs.bvh_stack > kBvhStack)) { printf("FAIL stack %u %u\n", fs.bvh_stack, deepest); return 1; }
+    // the candidate records are those of the meshes without a BVH
+    size_t want = 0;
+    for (uint32_t i = 0; i < n_objs; ++i)
+        if (fs.objs[i].kind == kKindMesh && fs.objs[i].bvh_root == kNoBvh) want += fs.objs[i].pair_count;
+    if (fs.cand_pairs.size() != want || !fs.cand_ok) { printf("FAIL cand %zu %zu\n", fs.cand_pairs.size(), want); return 1; }
+    printf("OK %zu %u %u\n", fs.bvh_meshes.size(), fs.bvh_stack, deepest);
+    return 0;
+}
+"""
+
+
+def test_flatten_tables_of_the_walk_queue(tmp_path):
+    """flatten_scene's tables for k_pass_cand<.., BVH> on mesh.json and cornell.json: tri_rank inverts rank_id, the BVH mesh
+    list holds the meshes with a BVH in visiting order, every triangle of such a mesh sits in exactly one leaf of at most
+    kBvhLeafPairs records inside the mesh's record range, the advertised stack depth covers the tree, and the candidate
+    records are exactly those of the meshes without a BVH."""
+    src = tmp_path / "f.cpp"
+    src.write_text(FLATTEN_SRC)
+    exe = str(tmp_path / "f")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ptlib.PKG, "csrc"), "-I", os.path.join(ptlib.ROOT, "include"),
+                           str(src), "-o", exe, "-L", ptlib.PKG, "-lptrace_hip", "-Wl,-rpath," + ptlib.PKG])
+    out = subprocess.check_output([exe, ptlib.scene_path("mesh"), ptlib.ROOT]).decode().split()
+    assert out[0] == "OK" and out[1] == "1" and int(out[2]) > int(out[3]) >= 5  # one BVH mesh; stack deeper than the tree
+    out = subprocess.check_output([exe, ptlib.scene_path("cornell"), ptlib.ROOT]).decode().split()
+    assert out[:2] == ["OK", "0"]
