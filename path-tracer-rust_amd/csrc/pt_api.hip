@@ -716,6 +716,7 @@ int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uin
     c->cand_ok = fs.cand_ok;
     c->scene.cand_staged = 0u;
     c->scene.surf_staged = 0u;
+    c->scene.surf_head = 0u;
     c->scene.walk_queue_cap = c->tune.walk_queue_cap;
 #ifdef PT_WALK_STATS
     if (!c->scene.stats) {

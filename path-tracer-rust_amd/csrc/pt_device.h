@@ -207,6 +207,7 @@ struct DevScene {
     uint32_t cand_scan;             // 1: k_pass uses the candidate scan
     uint32_t cand_staged;           // 1: the workgroup holds cand_pairs in LDS
     uint32_t surf_staged;           // 1: ... and surf (set per launch: launch_pass)
+    uint32_t surf_head;             // else: this many leading ranks of surf (the objects visited first) are staged
     uint32_t walk_queue_cap;        // 0, or a smaller capacity for the walk queue than its LDS area holds (tests: >= 128)
 #ifdef PT_WALK_STATS
     unsigned long long *stats;      // [16] counters of a -DPT_WALK_STATS build (tools/walk_stats.py): never in the shipped library
@@ -1457,8 +1458,14 @@ __device__ __forceinline__ Surface fetch_surface(const DevScene &S, vec3 o, vec3
 }
 
 // the same from the record of a visiting rank (candidate scan)
-__device__ __forceinline__ Surface fetch_surface_rank(const SurfRec *surf, vec3 o, vec3 d, float t, uint32_t rank) {
-    const SurfRec r = surf[rank];
+// `head` leading ranks may have a copy in LDS (`surf_lds`: k_pass_cand with walks, where the whole table does not fit)
+__device__ __forceinline__ Surface fetch_surface_rank(const SurfRec *surf, vec3 o, vec3 d, float t, uint32_t rank,
+                                                      const SurfRec *surf_lds = nullptr, uint32_t head = 0u) {
+    SurfRec r;
+    if (rank < head)
+        r = surf_lds[rank];
+    else
+        r = surf[rank];
     Surface s;
     s.x = o + d * t;  // mod.rs:430 / mod.rs:604
     s.n = (r.kind & 0x100u) ? mk(r.vx, r.vy, r.vz) : normalize(s.x - mk(r.vx, r.vy, r.vz));

@@ -537,6 +537,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
     uint32_t *lds_pix = s_tail_p + 4;
     for (uint32_t j = tid; j < mb; j += kBlock) lds_pix[j] = global_pixel(F, stream_pixel(F.n_streams, b, j));
     CandLds cand;
+    const SurfRec *surf_lds = nullptr;
+    uint32_t surf_head = 0u;
     {
         char *cbase = reinterpret_cast<char *>(dyn_lds) + pass_lds_cand_offset(m, DEFER);
         char *wbase = cbase + (size_t)(tid >> 6) * kCandWaveBytes;
@@ -558,6 +560,13 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
                 const uint32_t n_rows2 = (S.n_objs + S.n_tris) * (uint32_t)(sizeof(SurfRec) / 16u);
                 for (uint32_t k = tid; k < n_rows2; k += kBlock) dst2[k] = src2[k];
                 cand.surf = reinterpret_cast<const SurfRec *>(dst2);
+            } else if (S.surf_head != 0u) {  // the table is too large: only the ranks of the objects visited first
+                const uint4 *src2 = reinterpret_cast<const uint4 *>(S.surf);
+                uint4 *dst2 = dst + n_rows;
+                const uint32_t n_rows2 = S.surf_head * (uint32_t)(sizeof(SurfRec) / 16u);
+                for (uint32_t k = tid; k < n_rows2; k += kBlock) dst2[k] = src2[k];
+                surf_lds = reinterpret_cast<const SurfRec *>(dst2);
+                surf_head = S.surf_head;
             }
         }
     }
@@ -669,7 +678,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
             if (rank != 0xffffffffu) {
                 in.pix = lds_pix[word_pix(word)];
                 in.meta = pack_meta(s0 + word_sample(word), word_depth(word), word_branch(word));
-                const Surface sf = fetch_surface_rank(cand.surf, in.o, in.d, __uint_as_float((uint32_t)(key >> 32)), rank);
+                const Surface sf = fetch_surface_rank(cand.surf, in.o, in.d, __uint_as_float((uint32_t)(key >> 32)), rank, surf_lds, surf_head);
                 shade_surface<kShadeAll>(P, in, sf, so);
                 if (so.emits) add_radiance_lds(lds_acc, m, word_pix(word), so.contrib);
             }
@@ -760,7 +769,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
                         pr.thr = prev_thr;
                         pr.pix = lds_pix[word_pix(prev_word)];
                         pr.meta = pack_meta(s0 + word_sample(prev_word), word_depth(prev_word), word_branch(prev_word));
-                        const Surface sf = fetch_surface_rank(cand.surf, pr.o, pr.d, hit_t, rank);
+                        const Surface sf = fetch_surface_rank(cand.surf, pr.o, pr.d, hit_t, rank, surf_lds, surf_head);
                         shade_surface<DEFER ? kShadeDeferRefract : kShadeAll>(P, pr, sf, so);
                         if (so.emits) add_radiance_lds(lds_acc, m, word_pix(prev_word), so.contrib);
                     }
@@ -1364,7 +1373,14 @@ void launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const FrameParam
         S2.surf_staged = before + rec_cand + rec_surf <= budget ? 1u : 0u;
         // (without walks the records are staged whole or not at all; with walks the candidate records alone may be)
         const bool staged = bvh ? (S2.surf_staged || before + rec_cand <= budget + 8u * 1024u) : S2.surf_staged != 0u;
-        const size_t lds = before + (staged ? rec_cand + (S2.surf_staged ? rec_surf : 0u) : 0u);
+        // (walks, table too large: as many leading ranks as still fit - the objects visited first, the room of mesh.json)
+        S2.surf_head = 0u;
+        if (bvh && staged && !S2.surf_staged && before + rec_cand < budget) {
+            const size_t fit = (budget - before - rec_cand) / sizeof(SurfRec);
+            const size_t n_ranks = (size_t)S.n_objs + S.n_tris;
+            S2.surf_head = (uint32_t)(fit < n_ranks ? fit : n_ranks);
+        }
+        const size_t lds = before + (staged ? rec_cand + (S2.surf_staged ? rec_surf : (size_t)S2.surf_head * sizeof(SurfRec)) : 0u);
         // (more than 64 KB of dynamic LDS - wide deep trees with hundreds of pixels per stream - has to be asked for)
 #define PT_LAUNCH_CAND(ST, DF, BV)                                                                                     \
     do {                                                                                                               \
