@@ -116,6 +116,7 @@ struct pt_ctx {
     DevBuf<SurfRec> d_surf;
     bool cand_ok = false;
     uint32_t n_bvh_nodes = 0;
+    uint32_t n_cus = 0;  // compute units of the device (stream-count rounding)
     // Mesh.bounding_box of every object (12 object-local triangles each; Mesh::new's unless pt_ctx_set_mesh_bounds gave
     // the stored ones) and their device form (6 pair records per object), for intersect_bounds / orbit-point queries
     std::vector<pt_triangle> h_boxes;
@@ -292,6 +293,25 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
     uint32_t m = (uint32_t)((npix + k_target - 1) / k_target);
     if (m == 0) m = 1;
     if (m > kMaxStreamPixels) m = kMaxStreamPixels;
+    // A launch runs its workgroups in rounds of as many as the chip holds (four per CU); a stream's work grows with its m
+    // pixels, so a launch takes about ceil(K / resident) x m: among the m within -15 % / +20 % of the tuned size take the
+    // one for which that is smallest (cornell 1024x768: m = 21 -> 24, 37 450 streams in 36.6 rounds -> 32 768 in 32.0,
+    // 37.3 -> 37.7 G bounces/s).  Not for scenes with walks, whose streams differ too much in length for rounds to show
+    // (mesh.json: 24.0 rounds are slower than 25.6).
+    if (c->scene.cand_scan && c->scene.n_bvh_nodes == 0u && !c->tune.streams && c->n_cus != 0u && m >= 8u) {
+        const uint64_t resident = (uint64_t)c->n_cus * 4u;
+        uint32_t best_m = m;
+        uint64_t best_cost = ~0ull;
+        for (uint32_t mm = m - m * 15u / 100u; mm <= m + m / 5u && mm <= kMaxStreamPixels; ++mm) {
+            const uint64_t kk = (npix + mm - 1u) / mm;
+            const uint64_t cost = ((kk + resident - 1u) / resident) * mm;
+            if (cost < best_cost || (cost == best_cost && (mm > m ? mm - m : m - mm) < (best_m > m ? best_m - m : m - best_m))) {
+                best_cost = cost;
+                best_m = mm;
+            }
+        }
+        m = best_m;
+    }
     const uint32_t K = (uint32_t)((npix + m - 1) / m);
     // a primary ray has at most 4 descendants alive at one depth (two refract splits, mod.rs:760)
     const uint64_t cap64 = (4ull * m * spp_pass + kBlock - 1) / kBlock * kBlock;
@@ -598,6 +618,10 @@ int pt_ctx_create(int device, pt_ctx **out) {
     pt_ctx *c = new pt_ctx();
     c->device = device;
     c->tune = read_tuning();
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->n_cus = (uint32_t)cus;
+    }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         set_error(std::string("hipStreamCreate: ") + hipGetErrorString(e));
