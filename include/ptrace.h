@@ -221,6 +221,12 @@ int pt_mesh_bounding_box(const pt_triangle *tris, uint32_t n_tris, pt_triangle o
 int pt_ctx_numerics_probe(pt_ctx *ctx, const float *in, uint32_t n, float *out_sin, float *out_cos,
                           float *out_sqrt, float *out_rcp, uint32_t *out_philox);
 
+/* Diagnostics, exhaustive: the device's f_sqrt against the compiler's IEEE square root on all 2^32 binary32 bit patterns
+ * and its f_rcp against IEEE 1/d on every normal d with 2^-126 <= |d| <= 2^126 (the domain its callers keep to).
+ * out[0], out[1] = inputs whose results differ in bits (NaN == NaN) - both must be 0; out[2], out[3] = inputs compared.
+ * About a second of GPU time. */
+int pt_ctx_numerics_sweep(pt_ctx *ctx, uint64_t out[4]);
+
 /* The host instantiation of the shared numerics header's sincos (the same source the kernels compile). */
 void pt_host_sincos(float y, float *s, float *c);
 

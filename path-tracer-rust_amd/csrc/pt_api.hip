@@ -748,6 +748,12 @@ int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uin
         HIP_TRY(hipMemset(c->scene.stats, 0, 16 * sizeof(unsigned long long)));
     }
 #endif
+#ifdef PT_PHASE_STATS
+    if (!c->scene.phase_stats) {  // instrumented builds only: never freed
+        HIP_TRY(hipMalloc((void **)&c->scene.phase_stats, (kPhCount * 3 + 2) * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(c->scene.phase_stats, 0, (kPhCount * 3 + 2) * sizeof(unsigned long long)));
+    }
+#endif
     c->n_bvh_nodes = (uint32_t)fs.bvh_nodes.size();
     c->scene.bvh_nodes = c->d_nodes.p;
     c->scene.n_bvh_nodes = c->n_bvh_nodes;
@@ -1210,6 +1216,32 @@ int pt_ctx_numerics_probe(pt_ctx *c, const float *in, uint32_t n, float *out_sin
     return PT_OK;
 }
 
+int pt_ctx_numerics_sweep(pt_ctx *c, uint64_t out[4]) {
+    if (!c || !out) {
+        set_error("NULL argument");
+        return PT_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf<unsigned long long> d;
+    int rc = d.ensure(4);
+    if (rc) return rc;
+    hipError_t e = hipMemsetAsync(d.p, 0, 4 * sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) {
+        launch_numerics_sweep(c->stream, d.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    unsigned long long h[4] = {0, 0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpy(h, d.p, sizeof h, hipMemcpyDeviceToHost);
+    d.release();
+    if (e != hipSuccess) {
+        set_error(std::string("numerics sweep: ") + hipGetErrorString(e));
+        return PT_ERR_HIP;
+    }
+    for (int i = 0; i < 4; ++i) out[i] = h[i];
+    return PT_OK;
+}
+
 // one band on one device into the host framebuffer
 static int render_band_to_host(int dev, const pt_config *cfg, const pt_camera *cam, const pt_object *objs,
                                uint32_t n_objs, const pt_triangle *tris, uint32_t n_tris, float *out_rgb,
@@ -1341,6 +1373,17 @@ int pt_debug_walk_stats(pt_ctx *c, unsigned long long *out16) {
     hipMemcpy(out16, c->scene.stats, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     hipMemset(c->scene.stats, 0, 16 * sizeof(unsigned long long));
     return PT_OK;
+}
+#endif
+
+#ifdef PT_PHASE_STATS
+// instrumented builds only (tools/phase_budget.py): read and clear the phase counters; returns the number of phases
+int pt_debug_phase_stats(pt_ctx *c, unsigned long long *out, uint32_t cap) {
+    if (!c || !c->scene.phase_stats || cap < kPhCount * 3 + 2) return PT_ERR_INVALID;
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(out, c->scene.phase_stats, (kPhCount * 3 + 2) * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    (void)hipMemset(c->scene.phase_stats, 0, (kPhCount * 3 + 2) * sizeof(unsigned long long));
+    return (int)kPhCount;
 }
 #endif
 

@@ -6,11 +6,19 @@
 // point to point: a single all-gather of 9.4 MB (1024x768) / 805 MB (4096^2) per frame is the whole traffic, so nothing
 // here is bucketed or overlapped - the frame is complete when the collective starts.
 //
-// librccl is loaded with dlopen on first use (PT_RCCL_LIB, else librccl.so.1, else librccl.so): libptrace_hip.so has no
-// link-time dependency on it, hosts that never gather do not load it, and inside a process that already holds an RCCL
-// (torch's) the same soname resolves to that copy instead of a second one.
+// librccl is loaded with dlopen on first use: libptrace_hip.so has no link-time dependency on it (nor on its headers: the
+// five entry points and three types used are declared below as rccl.h declares them), and hosts that never gather do not
+// load it.  WHICH librccl matters: a communicator must run on the HIP runtime this library itself is bound to - it is
+// handed this library's streams and buffers.  A process may hold two HIP runtimes (a PyTorch wheel bundles its own
+// libamdhip64 / libhsa-runtime64 / librccl under torch/lib; whichever of torch and this library is loaded first decides
+// which runtime this library binds to, and the other copy may be mapped as well), and both RCCL copies carry the soname
+// librccl.so.1, so a dlopen by soname returns whichever copy was mapped first - in a process that loaded this library
+// before torch that is torch's RCCL on torch's runtime, and ncclCommInitRank fails ("unhandled cuda error").  So the
+// search order is: PT_RCCL_LIB (explicit override); then librccl.so.1 / librccl.so IN THE DIRECTORY OF THE libamdhip64 THIS
+// LIBRARY'S hipGetDeviceCount RESOLVES TO (dladdr), opened by full path - the sibling of our runtime, whatever else is mapped;
+// then the bare sonames.
 #include <dlfcn.h>
-#include <rccl/rccl.h>
+#include <link.h>
 
 #include <cstdlib>
 #include <cstring>
@@ -27,6 +35,16 @@ using namespace pt;
 
 namespace {
 
+// rccl.h (RCCL 2.x), the part used here
+typedef int ncclResult_t;  // enum: ncclSuccess = 0
+constexpr ncclResult_t ncclSuccess = 0;
+typedef struct ncclComm *ncclComm_t;
+typedef struct {
+    char internal[128];
+} ncclUniqueId;
+typedef int ncclDataType_t;  // enum: ncclFloat32 = 7
+constexpr ncclDataType_t ncclFloat = 7;
+
 struct Rccl {
     void *handle = nullptr;
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
@@ -35,17 +53,39 @@ struct Rccl {
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     std::string why;
+    std::string path;      // what was opened
+    std::string hip_path;  // the HIP runtime this library is bound to
+    int hip_runtimes = 0;  // objects named libamdhip64* mapped in the process
 };
+
+int count_hip(struct dl_phdr_info *info, size_t, void *data) {
+    if (info->dlpi_name && strstr(info->dlpi_name, "libamdhip64")) ++*(int *)data;
+    return 0;
+}
 
 Rccl &rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        const char *names[3] = {getenv("PT_RCCL_LIB"), "librccl.so.1", "librccl.so"};
+        std::string sib1, sib2;
+        Dl_info di;
+        if (dladdr((void *)&hipGetDeviceCount, &di) && di.dli_fname) {
+            r.hip_path = di.dli_fname;
+            const size_t slash = r.hip_path.rfind('/');
+            if (slash != std::string::npos) {
+                sib1 = r.hip_path.substr(0, slash + 1) + "librccl.so.1";
+                sib2 = r.hip_path.substr(0, slash + 1) + "librccl.so";
+            }
+        }
+        dl_iterate_phdr(count_hip, &r.hip_runtimes);
+        const char *names[5] = {getenv("PT_RCCL_LIB"), sib1.c_str(), sib2.c_str(), "librccl.so.1", "librccl.so"};
         for (const char *n : names) {
             if (!n || !*n) continue;
             r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-            if (r.handle) break;
+            if (r.handle) {
+                r.path = n;
+                break;
+            }
             r.why = dlerror();
         }
         if (!r.handle) return;
@@ -60,6 +100,13 @@ Rccl &rccl() {
         }
     });
     return r;
+}
+
+// which RCCL on which HIP runtime (appended to communicator errors: the usual cause is a mismatch of the two)
+std::string rccl_where() {
+    const Rccl &r = rccl();
+    return " [librccl: " + r.path + "; this library's HIP runtime: " + r.hip_path + "; libamdhip64 objects mapped: " +
+           std::to_string(r.hip_runtimes) + "]";
 }
 
 int need_rccl() {
@@ -106,7 +153,7 @@ struct pt_comm {
 extern "C" {
 
 int pt_comm_unique_id(uint8_t id[PT_COMM_ID_BYTES]) {
-    static_assert(sizeof(ncclUniqueId) == PT_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    static_assert(sizeof(ncclUniqueId) == PT_COMM_ID_BYTES, "ncclUniqueId is 128 bytes (NCCL_UNIQUE_ID_BYTES)");
     if (!id) {
         set_error("id is NULL");
         return PT_ERR_INVALID;
@@ -145,7 +192,7 @@ int pt_comm_create(int device, int rank, int n_ranks, const uint8_t id[PT_COMM_I
     memcpy(&u, id, sizeof u);
     ncclResult_t r = rccl().CommInitRank(&c->comm, n_ranks, u, rank);
     if (r != ncclSuccess) {
-        set_error(std::string("ncclCommInitRank: ") + rccl().GetErrorString(r));
+        set_error(std::string("ncclCommInitRank: ") + rccl().GetErrorString(r) + rccl_where());
         delete c;
         return PT_ERR_COMM;
     }

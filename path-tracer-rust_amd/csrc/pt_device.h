@@ -126,7 +126,10 @@ struct alignas(16) FlatPairRec {
 };
 constexpr uint32_t kNoPair = 0xffffffffu;
 constexpr float kGrazing = 1.0f / 64.0f;  // |d_a| below this: the filter does not judge, the exact test does
-constexpr uint32_t kCandQueueCap = 192;   // per-wave candidate ring (u16 entries): 63 left over + 2 x 64 pushed by one filter step
+constexpr uint32_t kCandQueueCap = 256;   // per-wave candidate ring (u16 entries): 63 left over + 2 x 64 pushed by one filter step
+                                          // = 191 at most; a power of two, so that positions wrap with one v_and instead of
+                                          // two compare / select pairs per push (4-cycle instructions, eight pushes per trip)
+static_assert((kCandQueueCap & (kCandQueueCap - 1u)) == 0u && kCandQueueCap >= 192u, "ring positions wrap by masking");
 constexpr uint32_t kCandMaxPairs = 512;   // candidate records are numbered in 9 bits of a queue entry
 // What the exact test of a candidate needs, in one record (a copy of the TriPairRec with ids replaced by visiting ranks,
 // plus the bounding-sphere gate of the mesh the two triangles belong to): 7 rows of 16 bytes, gathered per lane from
@@ -212,7 +215,33 @@ struct DevScene {
 #ifdef PT_WALK_STATS
     unsigned long long *stats;      // [16] counters of a -DPT_WALK_STATS build (tools/walk_stats.py): never in the shipped library
 #endif
+#ifdef PT_PHASE_STATS
+    unsigned long long *phase_stats;  // [kPhCount][3] + [2] (wave lifetimes: s_memtime, s_memrealtime) of a -DPT_PHASE_STATS build
+#endif
 };
+#ifdef PT_PHASE_STATS
+// Diagnostic build only (tools/phase_budget.py -> profiles/r03_*_phase_budget.json; never in the shipped library): the
+// wave's lifetime inside k_pass_cand split by PHASE.  PT_PHASE(id) stamps s_memtime (shader cycles) and books the cycles
+// since the last stamp to the phase the wave was in, per wave in LDS (one active lane does the bookkeeping); the phase
+// being entered gets one entry and popcount(EXEC) lanes.  The totals go to DevScene.phase_stats when the workgroup ends,
+// together with the wave's whole lifetime in s_memtime and s_memrealtime ticks (100 MHz): the clock the chip held.
+enum : uint32_t {
+    kPhOther = 0, kPhLoad, kPhSpheres, kPhFilter, kPhBatch, kPhFinish, kPhSurface, kPhRng, kPhDiffuse, kPhSpecular, kPhGlass,
+    kPhAppend, kPhDefer, kPhBarrier, kPhWants, kPhWalkGate, kPhWalkBox, kPhWalkLeaf, kPhPrimary, kPhEmit, kPhCount
+};
+struct PhaseLds {
+    unsigned long long state[4];              // per wave of the workgroup: current phase << 32 | last stamp
+    unsigned long long cyc[4][kPhCount];      // cycles
+    unsigned long long cnt[4][kPhCount];      // entries << 32 | lanes at entry
+};
+#define PT_PHASE(id) ::pt::phase_to(id)
+// keeps a value's computation in front of the next stamp (an empty asm that reads it)
+#define PT_PHASE_PIN(v) asm volatile("" ::"v"(v))
+#else
+#define PT_PHASE(id) do { } while (0)
+#define PT_PHASE_PIN(v) do { } while (0)
+#endif
+
 #ifdef PT_WALK_STATS
 // v is wave-uniform; one lane of the active ones adds it
 #define PT_WSTAT(S, i, v)                                                                               \
@@ -300,6 +329,63 @@ struct HitRec {
 
 #if defined(__HIPCC__)
 
+#ifdef PT_PHASE_STATS
+__device__ __forceinline__ PhaseLds &phase_lds() {
+    __shared__ PhaseLds s;
+    return s;
+}
+// s_memtime through volatile asm: the builtin may be hoisted above a divergent branch whose other side stamps too, and the
+// per-wave state word in LDS is written by whichever lane is the first active one - every access to it is volatile.
+// One stamp = s_memtime, one LDS read, two LDS adds without return, one LDS write by one lane: about a dozen instructions
+// (charged to the phase being entered).
+__device__ __forceinline__ uint32_t phase_clock() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t));
+    return (uint32_t)t;
+}
+__device__ __forceinline__ void phase_to(uint32_t id) {
+    PhaseLds &P = phase_lds();
+    const uint32_t w = threadIdx.x >> 6;
+    const uint64_t m = __builtin_amdgcn_ballot_w64(true);
+    const uint32_t now = phase_clock();
+    if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m)) {
+        const unsigned long long st = *(volatile unsigned long long *)&P.state[w];
+        atomicAdd(&P.cyc[w][(uint32_t)(st >> 32)], (unsigned long long)(now - (uint32_t)st));
+        atomicAdd(&P.cnt[w][id], (1ull << 32) | (unsigned long long)__builtin_popcountll(m));
+        *(volatile unsigned long long *)&P.state[w] = ((unsigned long long)id << 32) | now;
+    }
+}
+// first / last thing a workgroup does
+__device__ __forceinline__ void phase_begin(unsigned long long *t0, unsigned long long *r0) {
+    PhaseLds &P = phase_lds();
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (uint32_t k = lane; k < kPhCount; k += 64u) {
+        *(volatile unsigned long long *)&P.cyc[w][k] = 0ull;
+        *(volatile unsigned long long *)&P.cnt[w][k] = 0ull;
+    }
+    *t0 = __builtin_amdgcn_s_memtime();
+    *r0 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0u) *(volatile unsigned long long *)&P.state[w] = ((unsigned long long)kPhOther << 32) | (uint32_t)*t0;
+}
+__device__ __forceinline__ void phase_end(unsigned long long *out, unsigned long long t0, unsigned long long r0) {
+    phase_to(kPhOther);
+    PhaseLds &P = phase_lds();
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (uint32_t k = lane; k < kPhCount; k += 64u) {
+        const unsigned long long c = *(volatile unsigned long long *)&P.cyc[w][k], n = *(volatile unsigned long long *)&P.cnt[w][k];
+        if (c) atomicAdd(out + 3u * k, c);
+        if (n) {
+            atomicAdd(out + 3u * k + 1u, n >> 32);
+            atomicAdd(out + 3u * k + 2u, n & 0xffffffffull);
+        }
+    }
+    if (lane == 0u) {
+        atomicAdd(out + kPhCount * 3u, (unsigned long long)(__builtin_amdgcn_s_memtime() - t0));
+        atomicAdd(out + kPhCount * 3u + 1u, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - r0));
+    }
+}
+#endif
+
 // two f32 lanes per register pair: arithmetic on it compiles to v_pk_mul_f32 / v_pk_add_f32 (each half an
 // IEEE operation, no fusion under -ffp-contract=off)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -331,17 +417,13 @@ __device__ __forceinline__ f32x2 ld2(const float (&p)[2]) {
     f32x2 r = {p[0], p[1]};
     return r;
 }
-// f_rcp of both halves: the native reciprocals are per half, the six refinement fmas run packed (v_pk_fma_f32);
-// every half goes through exactly f_rcp's sequence of IEEE operations, so the results are f_rcp's.
+// f_rcp of both halves: the native reciprocals are per half, the Newton step runs packed (v_pk_fma_f32); every half goes
+// through exactly f_rcp's sequence of IEEE operations, so the results are f_rcp's.
 __device__ __forceinline__ f32x2 f_rcp2(f32x2 d) {
     const f32x2 one = splat2(1.0f);
     const f32x2 r0 = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
     const f32x2 e0 = __builtin_elementwise_fma(-d, r0, one);
-    const f32x2 r1 = __builtin_elementwise_fma(e0, r0, r0);
-    const f32x2 e1 = __builtin_elementwise_fma(-d, r1, one);
-    const f32x2 q1 = __builtin_elementwise_fma(e1, r1, r1);
-    const f32x2 e2 = __builtin_elementwise_fma(-d, q1, one);
-    return __builtin_elementwise_fma(e2, r1, q1);
+    return __builtin_elementwise_fma(e0, r0, r0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -786,6 +868,7 @@ __device__ __forceinline__ void bvh_closest_queue(const DevScene &S, NodePtr nod
     for (;;) {
         if (q_count == 0u && n_leaf == 0u) break;
         if (q_count != 0u) {
+            PT_PHASE(kPhWalkBox);
             // (smaller batches - closer to depth-first order, fewer boxes tested - lose: 48 items 18.5, 32 items 17.1 against
             // 19.3 G bounces/s on mesh.json; so do leaf batches started at 32 waiting leaves: 18.7)
             const uint32_t c = q_count < n_act ? q_count : n_act;
@@ -842,6 +925,7 @@ __device__ __forceinline__ void bvh_closest_queue(const DevScene &S, NodePtr nod
         // a dense batch of leaf tests whenever as many leaves wait as the wave has workers (before the next box tests: a hit
         // tightens its owner's bound); what is left when the queue is empty.  The most recent leaves first.
         while (n_leaf >= n_act || (q_count == 0u && n_leaf != 0u)) {
+            PT_PHASE(kPhWalkLeaf);
             const uint32_t cnt = n_leaf < n_act ? n_leaf : n_act;
             bool valid = my < cnt;
             uint2 e = make_uint2(lane, 0u);
@@ -877,6 +961,7 @@ __device__ __forceinline__ void bvh_closest_queue(const DevScene &S, NodePtr nod
             }
         }
     }
+    PT_PHASE(kPhWalkGate);
     if (walk) {
         const unsigned long long key = load_key(&keys[lane]);
         if ((uint32_t)key != 0xffffffffu) {
@@ -1200,11 +1285,10 @@ __device__ __forceinline__ unsigned long long cand_spheres(const DevScene &S, ve
 // from its slot in LDS (k_pass_cand keeps the rays of the two chunks in flight there).
 template <bool STAGED>
 __device__ __forceinline__ void cand_batch(const DevScene &S, const CandLds &L, CandRing &R, uint32_t lane, uint32_t count) {
+    PT_PHASE(kPhBatch);
     const bool valid = lane < count;
-    uint32_t at = R.head + lane;
-    at = at >= kCandQueueCap ? at - kCandQueueCap : at;
-    R.head += count;
-    R.head = R.head >= kCandQueueCap ? R.head - kCandQueueCap : R.head;
+    const uint32_t at = (R.head + lane) & (kCandQueueCap - 1u);
+    R.head = (R.head + count) & (kCandQueueCap - 1u);
     R.count -= count;
     if (valid) {
         const uint32_t ent = (uint32_t)L.queue[at];
@@ -1258,22 +1342,25 @@ __device__ __forceinline__ void cand_filter_and_drain(const DevScene &S, const C
         const uint32_t base = R.head + R.count;
         const uint32_t me = lane | (par << 6);
         if (c0) {
-            uint32_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
-            at = at >= kCandQueueCap ? at - kCandQueueCap : at;
-            at = at >= kCandQueueCap ? at - kCandQueueCap : at;
+            const uint32_t at = (base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))) & (kCandQueueCap - 1u);
             L.queue[at] = (uint16_t)(me | (q0 << 7));
         }
         if (c1) {
-            uint32_t at = base + n0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
-            at = at >= kCandQueueCap ? at - kCandQueueCap : at;
-            at = at >= kCandQueueCap ? at - kCandQueueCap : at;
+            const uint32_t at = (base + n0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u))) & (kCandQueueCap - 1u);
             L.queue[at] = (uint16_t)(me | (q1 << 7));
         }
         R.count += n0 + (uint32_t)__builtin_popcountll(m1);
     };
     auto drain = [&]() {
+#ifdef PT_PHASE_STATS
+        const bool any = R.count >= 64u;
+#endif
         while (R.count >= 64u) cand_batch<STAGED>(S, L, R, lane, 64u);
+#ifdef PT_PHASE_STATS
+        if (any) PT_PHASE(kPhFilter);
+#endif
     };
+    PT_PHASE(kPhFilter);
     const vec3 inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
     for (uint32_t p = 0; p < S.n_flat_pairs; ++p) {
         const FlatPairRec f = ld_uniform(S.flat_pairs + p);
@@ -1341,6 +1428,7 @@ __device__ __forceinline__ bool bvh_wants(const DevScene &S, vec3 o, vec3 d, flo
     //  * the slab test with approximate reciprocals (v_rcp_f32: 1 ulp) instead of correctly rounded divisions; each slab
     //    distance is then off by a relative 2^-22 at most, which the comparisons allow for (entry distance scaled down,
     //    exit distance and bound scaled up by 4e-7 each - on top of the pads the boxes carry for the exact test).
+    PT_PHASE(kPhWants);
     bool want = false;
     const float big = 1e18f;
     const vec3 inv = mk(__builtin_fmaxf(__builtin_fminf(__builtin_amdgcn_rcpf(d.x), big), -big),
@@ -1381,6 +1469,7 @@ __device__ __forceinline__ bool bvh_wants(const DevScene &S, vec3 o, vec3 d, flo
 __device__ __forceinline__ unsigned long long walk_deferred_keys(const DevScene &S, vec3 o, vec3 d, const WalkQueue &Q,
                                                                  unsigned long long key, unsigned long long *wave_keys) {
     for (uint32_t q = 0; q < S.n_bvh_meshes; ++q) {
+        PT_PHASE(kPhWalkGate);
         const BvhMeshRec bm = ld_uniform(S.bvh_meshes + q);
         const vec3 op = mk(bm.cx, bm.cy, bm.cz) - o;
         const float b = dot(op, d);
@@ -1497,6 +1586,7 @@ __device__ __forceinline__ void shade_surface(const Params &F, const PathRay &in
         out.emits = false;
         return;
     }
+    PT_PHASE(kPhRng);
     const vec3 d = in.d;
     const vec3 n = sf.n;
     const vec3 nl = dot(n, d) < 0.0f ? n : n * -1.0f;  // normal_towards_ray
@@ -1522,7 +1612,12 @@ __device__ __forceinline__ void shade_surface(const Params &F, const PathRay &in
     int n_rays = alive ? 1 : 0;
     vec3 d0 = d, thr0 = thr, d1 = d, thr1 = thr;
 
+    PT_PHASE_PIN(rnd.a);
+    PT_PHASE_PIN(rnd.b);
+    PT_PHASE_PIN(rnd.c);
+    PT_PHASE_PIN(thr.x);
     if (MODE != kShadeRefractOnly && sf.reflect == kDiffuse) {  // mod.rs:687-715
+        PT_PHASE(kPhDiffuse);
         const float r1 = (2.0f * 3.141592653589793f) * unit_f32(rnd.b);
         const float r2 = unit_f32(rnd.c);
         const float r2s = f_sqrt(r2);
@@ -1533,9 +1628,11 @@ __device__ __forceinline__ void shade_surface(const Params &F, const PathRay &in
         sincos_f32(r1, &sn, &cs);
         d0 = normalize(uu * cs * r2s + vv * sn * r2s + w * f_sqrt(1.0f - r2));
     } else {
+        PT_PHASE(kPhSpecular);
         const vec3 refl = d - n * 2.0f * dot(n, d);  // mod.rs:722-723 / 733-734
         d0 = refl;
         if (MODE == kShadeRefractOnly || sf.reflect == kRefract) {  // mod.rs:729-788
+            PT_PHASE(kPhGlass);
             const bool into = dot(n, nl) > 0.0f;
             const float nc = 1.0f, nt = 1.5f;
             const float nnt = into ? nc / nt : nt / nc;
@@ -1567,6 +1664,10 @@ __device__ __forceinline__ void shade_surface(const Params &F, const PathRay &in
             }
         }
     }
+    PT_PHASE_PIN(d0.x);
+    PT_PHASE_PIN(d0.y);
+    PT_PHASE_PIN(d0.z);
+    PT_PHASE(kPhFinish);
     out.d0 = d0;
     out.thr0 = thr0;
     out.d1 = d1;

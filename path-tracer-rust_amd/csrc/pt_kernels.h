@@ -47,6 +47,7 @@ void launch_query(hipStream_t st, const DevScene &S, const float *o, const float
 // mode 0: intersect_bounds of one object; mode 1: get_orbit_point (see k_bounds)
 void launch_bounds(hipStream_t st, const DevScene &S, const TriPairRec *boxes, uint32_t mode, uint32_t object, const float *o,
                    const float *d, uint32_t n, int32_t *hit, float *t, float *x, float *nrm, int32_t *object_id);
+void launch_numerics_sweep(hipStream_t st, unsigned long long *out4);
 void launch_numerics(hipStream_t st, const float *in, uint32_t n, float *out_sin, float *out_cos, float *out_sqrt,
                      float *out_rcp, uint32_t *out_philox);
 

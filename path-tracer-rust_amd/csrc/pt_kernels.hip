@@ -532,6 +532,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
     const uint32_t b = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
     const uint32_t mb = stream_pixel_count(F.npix, F.n_streams, b);  // <= m
     if (mb == 0u) return;
+#ifdef PT_PHASE_STATS
+    unsigned long long ph_t0, ph_r0;
+    phase_begin(&ph_t0, &ph_r0);
+#endif
     for (uint32_t k = tid; k < 3u * m; k += kBlock) lds_acc[k] = 0ull;
     if (tid == 0) s_tail_p[0] = s_tail_p[1] = 0u;
     uint32_t *lds_pix = s_tail_p + 4;
@@ -606,6 +610,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
     StreamSlice qout{};
     uint32_t *tail_p = nullptr;
     auto append = [&](const ShadeOut &so, uint32_t word) {
+        PT_PHASE(kPhAppend);
         const uint64_t m1 = __builtin_amdgcn_ballot_w64(so.n_rays >= 1);
         const uint64_t m2 = __builtin_amdgcn_ballot_w64(so.n_rays == 2);
         const uint32_t c1 = (uint32_t)__builtin_popcountll(m1), c2 = (uint32_t)__builtin_popcountll(m2);
@@ -639,6 +644,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
         so.n_rays = 0;
         so.emits = false;
         uint32_t word = 0;
+        PT_PHASE(kPhDefer);
         if (valid) {
             const float4 a = dbuf[e], bq = dbuf[kCandDeferCap + e], cq = dbuf[2u * kCandDeferCap + e];
             PathRay in;
@@ -650,6 +656,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
             in.meta = pack_meta(s0 + word_sample(word), word_depth(word), word_branch(word));
             const Surface sf = fetch_surface_rank(cand.surf, in.o, in.d, cq.z, __float_as_uint(cq.w));  // (t, rank) as parked
             shade_surface<kShadeRefractOnly>(P, in, sf, so);
+            PT_PHASE(kPhEmit);
             if (so.emits) add_radiance_lds(lds_acc, m, word_pix(word), so.contrib);
         }
         append(so, word);
@@ -663,6 +670,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
         so.n_rays = 0;
         so.emits = false;
         uint32_t word = 0;
+        PT_PHASE(kPhLoad);
         if (valid) {
             const uint32_t i = p_idx[e];
             PathRay in;
@@ -678,8 +686,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
             if (rank != 0xffffffffu) {
                 in.pix = lds_pix[word_pix(word)];
                 in.meta = pack_meta(s0 + word_sample(word), word_depth(word), word_branch(word));
+                PT_PHASE(kPhSurface);
                 const Surface sf = fetch_surface_rank(cand.surf, in.o, in.d, __uint_as_float((uint32_t)(key >> 32)), rank, surf_lds, surf_head);
                 shade_surface<kShadeAll>(P, in, sf, so);
+                PT_PHASE(kPhEmit);
                 if (so.emits) add_radiance_lds(lds_acc, m, word_pix(word), so.contrib);
             }
         }
@@ -692,11 +702,18 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
         qin = slice_of((depth & 1u) ? q1 : q0, base);  // level 0 is never stored
         level = depth;
         qout = slice_of((depth & 1u) ? q0 : q1, base);
+        PT_PHASE(kPhBarrier);
         __syncthreads();  // level `depth` of the stream is complete and visible (and, the first time, the staged records)
+        PT_PHASE(kPhOther);
         if (tid == 0) s_tail_p[(depth + 1u) & 1u] = 0u;
         tail_p = s_tail_p + (depth & 1u);
-        total += n;
+        // (Carrying a level's partial chunk over to the next level instead of tracing it half empty - rays keep their own depth
+        // in the bookkeeping word, so a level may mix depths - was built and measured: the partial chunks are 4.8 % of all
+        // chunk trips' lanes (profiles/r03_k_pass_cand_phase_budget.json), but every carried ray lengthens its stream by a
+        // level, and the extra, nearly empty levels at the end of a stream cost what the full chunks saved: cornell 39.3
+        // against 39.6 G bounces/s, mesh.json 21.0 against 22.4; same images.)
         const uint32_t n_chunks = (n + kBlock - 1u) / kBlock;
+        total += n;
         vec3 prev_thr = mk(0.0f, 0.0f, 0.0f);  // what the ray started in the trip before still needs from registers
         uint32_t prev_word = 0;
         bool prev_valid = false;
@@ -708,7 +725,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
             uint32_t word = 0;
             const uint32_t pending = ring.count;  // entries of chunk it - 1 still queued (< 64)
             bool ran_batch = false;
-            if (it < n_chunks) {
+            // (a wave none of whose lanes holds a ray of this chunk - the partial last chunk of a level - starts nothing: its
+            // slots are never read, prev_valid will be false for every lane)
+            if (it < n_chunks && it * kBlock + (tid & ~63u) < n) {
+                PT_PHASE(depth == 0u ? kPhPrimary : kPhLoad);
                 PathRay in;
                 in.o = in.d = in.thr = mk(0.0f, 0.0f, 0.0f);
                 if (cur_valid) {
@@ -725,6 +745,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
                 cand.ray_a[slot] = make_float4(in.o.x, in.o.y, in.o.z, in.d.x);
                 cand.ray_b[slot] = make_float2(in.d.y, in.d.z);
                 float bound;
+                PT_PHASE(kPhSpheres);
                 const unsigned long long key0 = cand_spheres(S, in.o, in.d, &bound);
                 cand.keys[slot] = cur_valid ? key0 : kKeyMiss;
                 const uint32_t before = ring.head;
@@ -732,9 +753,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
                 ran_batch = ring.head != before;
             }
             if (it > 0u) {
+                PT_PHASE(kPhFinish);
                 // chunk it - 1: its candidates were the oldest entries of the ring; if no full batch ran in this trip (few
                 // candidates, or the flushing trip) run what is queued now
                 if (pending != 0u && !ran_batch) cand_batch<STAGED>(S, cand, ring, lane, ring.count);
+                PT_PHASE(kPhFinish);
                 ShadeOut so;
                 so.n_rays = 0;
                 so.emits = false;
@@ -769,8 +792,14 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
                         pr.thr = prev_thr;
                         pr.pix = lds_pix[word_pix(prev_word)];
                         pr.meta = pack_meta(s0 + word_sample(prev_word), word_depth(prev_word), word_branch(prev_word));
+                        PT_PHASE(kPhSurface);
                         const Surface sf = fetch_surface_rank(cand.surf, pr.o, pr.d, hit_t, rank, surf_lds, surf_head);
+                        PT_PHASE_PIN(sf.n.x);
+                        PT_PHASE_PIN(sf.n.y);
+                        PT_PHASE_PIN(sf.n.z);
+                        PT_PHASE_PIN(sf.x.x);
                         shade_surface<DEFER ? kShadeDeferRefract : kShadeAll>(P, pr, sf, so);
+                        PT_PHASE(kPhEmit);
                         if (so.emits) add_radiance_lds(lds_acc, m, word_pix(prev_word), so.contrib);
                     }
                 }
@@ -798,6 +827,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
                         walk_batch(n_park + lane, lane < cnt);
                     }
                 }
+                PT_PHASE(kPhDefer);
                 const uint64_t md = DEFER ? __builtin_amdgcn_ballot_w64(so.deferred) : 0ull;
                 if (DEFER && md != 0ull) {
                     if (so.deferred) {
@@ -814,6 +844,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
                     shade_deferred(n_defer + lane, lane < cnt);
                 }
             }
+            PT_PHASE(kPhOther);
             prev_thr = cur_thr;
             prev_word = word;
             prev_valid = cur_valid;
@@ -822,7 +853,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
             shade_deferred(lane, lane < n_defer);
             n_defer = 0u;
         }
+        PT_PHASE(kPhBarrier);
         __syncthreads();  // every append of this level is counted
+        PT_PHASE(kPhOther);
         const uint32_t tail = *tail_p;
         n = tail < cap ? tail : cap;
     }
@@ -835,6 +868,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
         const unsigned long long v = lds_acc[c * m + p];
         if (v) acc[(size_t)c * plane + (size_t)b * m + p] += v;
     }
+#ifdef PT_PHASE_STATS
+    phase_end(S.phase_stats, ph_t0, ph_r0);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1317,6 +1353,29 @@ __global__ void k_numerics(const float *__restrict__ in, uint32_t n, float *__re
     out_philox[4 * i + 3] = r.d;
 }
 
+// Exhaustive form of the same check for the two short sequences: f_sqrt against the compiler's IEEE square root on ALL
+// 2^32 bit patterns, f_rcp against the compiler's IEEE division 1/d on every normal d with 2^-126 <= |d| <= 2^126 (its
+// domain).  out[0] / out[1]: inputs whose results differ in bits (NaN == NaN); out[2] / out[3]: inputs compared.
+__global__ __launch_bounds__(256) void k_numerics_sweep(unsigned long long *__restrict__ out) {
+    unsigned long long bad_s = 0, bad_r = 0, n_s = 0, n_r = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += (uint64_t)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float((uint32_t)i);
+        const uint32_t a = (uint32_t)i & 0x7fffffffu;
+        const uint32_t gs = __float_as_uint(f_sqrt(x)), ws = __float_as_uint(__builtin_sqrtf(x));
+        const bool nan_both = (gs & 0x7fffffffu) > 0x7f800000u && (ws & 0x7fffffffu) > 0x7f800000u;
+        bad_s += (gs != ws && !nan_both) ? 1u : 0u;
+        ++n_s;
+        if (a >= 0x00800000u && a <= 0x7e800000u) {  // 2^-126 <= |d| <= 2^126
+            bad_r += (__float_as_uint(f_rcp(x)) != __float_as_uint(1.0f / x)) ? 1u : 0u;
+            ++n_r;
+        }
+    }
+    if (bad_s) atomicAdd(out + 0, bad_s);
+    if (bad_r) atomicAdd(out + 1, bad_r);
+    atomicAdd(out + 2, n_s);
+    atomicAdd(out + 3, n_r);
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 void launch_generate(hipStream_t st, uint32_t K, const FrameParams &F, const RayQueue &q, uint32_t *cnt0,
                      uint32_t cap, uint32_t s0, uint32_t s_here, uint32_t m) {
@@ -1448,6 +1507,9 @@ void launch_bounds(hipStream_t st, const DevScene &S, const TriPairRec *boxes, u
     if (grid > 4096u) grid = 4096u;
     if (grid == 0u) grid = 1u;
     hipLaunchKernelGGL(k_bounds, dim3(grid), dim3(kBlock), 0, st, S, boxes, mode, object, o, d, n, hit, t, x, nrm, object_id);
+}
+void launch_numerics_sweep(hipStream_t st, unsigned long long *out4) {
+    hipLaunchKernelGGL(k_numerics_sweep, dim3(8192), dim3(256), 0, st, out4);
 }
 void launch_numerics(hipStream_t st, const float *in, uint32_t n, float *out_sin, float *out_cos, float *out_sqrt,
                      float *out_rcp, uint32_t *out_philox) {

@@ -51,38 +51,33 @@ PT_HD vec3 cross(vec3 a, vec3 b) {
 }
 PT_HD float f_abs(float x) { return __builtin_fabsf(x); }
 // IEEE correctly rounded square root and reciprocal on both sides (x86: sqrtss / divss).
-// On the device these are hipcc's own correctly-rounded expansions (-fhip-fp32-correctly-rounded-divide-sqrt)
-// with the input-scaling steps taken out of the common path:
-//   f_sqrt: v_sqrt_f32 (<= 1 ulp) then the two-neighbour fma residual test, exactly as LLVM lowers llvm.sqrt.f32;
-//           LLVM first multiplies inputs below 2^-96 by 2^32 (the residuals would underflow).  Here the whole
-//           wave takes the full llvm.sqrt.f32 path only if some lane really holds 0 < x < 2^-96 (a tangent ray's
-//           discriminant can), otherwise the 5 scaling instructions are skipped.  +-0, +inf, NaN and negative
-//           inputs come out of the short path as IEEE requires (checked lane by lane in the tests).
-//   f_rcp : LLVM's f32 division with numerator 1: v_rcp_f32, one Newton step, then the quotient/residual fmas.
-//           v_div_scale / v_div_fmas / v_div_fixup only matter when the divisor is denormal, zero, inf, NaN or
-//           |d| > 2^126; callers guarantee a normal in-range divisor wherever the result is used (vector lengths
-//           of scene-scale vectors; determinants that passed |det| >= 1e-4), so the three are dropped.
+// On the device they are SHORT sequences around the native approximations, each proven equal to the compiler's IEEE
+// expansion (-fhip-fp32-correctly-rounded-divide-sqrt) on every input of its fast-path domain by exhaustive comparison
+// on the hardware (tools/rounding_search.hip over all 2^32 bit patterns -> profiles/r03_rounding_search.json; the same
+// sweep runs through the library in the GPU tests: pt_ctx_numerics_sweep):
+//   f_sqrt: v_rsq_f32, s = x*r, h = r/2, one residual d = fma(-s, s, x), result fma(d, h, s) - 16 issue cycles instead of the
+//           32 of v_sqrt_f32 + two-neighbour residual test (round 1-2) - exact for every x in [2^-96, largest float]; negative
+//           x gives NaN as IEEE wants.  Zero, denormals, normals below 2^-96 (the residual would underflow: a tangent ray's
+//           discriminant can be that small), infinities and NaN take the compiler's full path: the whole wave does when
+//           some lane holds one (one integer range test on |x|'s bits per call).
+//   f_rcp : v_rcp_f32 and ONE Newton step - exact for every normal d with 2^-126 <= |d| <= 2^126 (round 1-2 ran LLVM's
+//           division with numerator 1, seven operations).  Callers guarantee a normal in-range divisor wherever the result
+//           is used (vector lengths of scene-scale vectors; determinants that passed |det| >= 1e-4).
 // HIP's __fsqrt_rn / __frcp_rn are the 1-ulp native ops and are not usable (tests caught it).
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ float f_sqrt(float x) {
-    // |x| < 2^-96 (one compare with the |.| source modifier): tiny inputs of either sign - the native op flushes
-    // -denormal to -0 where IEEE wants NaN - and, harmlessly, +-0 take the full path; NaN does not
-    if (__builtin_amdgcn_ballot_w64(f_abs(x) < 0x1p-96f) != 0ull) return __builtin_sqrtf(x);
-    const float s = __builtin_amdgcn_sqrtf(x);
-    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
-    const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
-    float r = r_dn <= 0.0f ? s_dn : s;
-    r = r_up > 0.0f ? s_up : r;
-    return r;
+    // fast path iff 2^-96 <= |x| < inf: (bits(|x|) - bits(2^-96)) < (bits(inf) - bits(2^-96)) as unsigned integers
+    const uint32_t off = (__float_as_uint(x) & 0x7fffffffu) - 0x0f800000u;
+    if (__builtin_amdgcn_ballot_w64(off >= 0x70000000u) != 0ull) return __builtin_sqrtf(x);
+    const float r = __builtin_amdgcn_rsqf(x);
+    const float s = x * r, h = 0.5f * r;
+    const float d = __builtin_fmaf(-s, s, x);
+    return __builtin_fmaf(d, h, s);
 }
 __device__ __forceinline__ float f_rcp(float d) {
     const float r0 = __builtin_amdgcn_rcpf(d);
     const float e0 = __builtin_fmaf(-d, r0, 1.0f);
-    const float r1 = __builtin_fmaf(e0, r0, r0);
-    const float e1 = __builtin_fmaf(-d, r1, 1.0f);
-    const float q1 = __builtin_fmaf(e1, r1, r1);
-    const float e2 = __builtin_fmaf(-d, q1, 1.0f);
-    return __builtin_fmaf(e2, r1, q1);
+    return __builtin_fmaf(e0, r0, r0);
 }
 #else
 PT_HD float f_sqrt(float x) { return __builtin_sqrtf(x); }
