@@ -172,11 +172,8 @@ def main():
     coll_dev = dev if (dist_backend == "nccl" and not abi_gather) else torch.device("cpu")
     comm = None
     if abi_gather:
-        # one RCCL in the process: torch has loaded its bundled copy (and its HIP runtime, which libptrace_hip.so then
-        # shares by soname), so the C ABI is pointed at that copy rather than at /opt/rocm's
-        torch_rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        if os.path.exists(torch_rccl):
-            os.environ.setdefault("PT_RCCL_LIB", torch_rccl)
+        # (libptrace_hip.so finds the RCCL that belongs to the HIP runtime it is bound to - here torch's, loaded first - by
+        # itself: csrc/pt_comm.hip)
         ident = [pkg.Comm.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ident, src=0)
         comm = pkg.Comm(dev_index, rank, world, ident[0])

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 3
+#define PT_ABI_VERSION 4
 
 /* status codes (reference behaviour: unwrap() panics, mod.rs:96,309,1032,1042,1093) */
 #define PT_OK 0
@@ -132,9 +132,11 @@ typedef struct pt_stats {
     double ms_intersect; /* HIP-event time summed over those launches (only if PT profiling on) */
 } pt_stats;
 
-/* Progress callback: fraction in [0,1], between passes, at most every pt_config.progress_ms, and once with 1.0 when the
- * frame is complete.  pt_ctx_render invokes it on the calling thread; pt_render_multi and PT_FLAG_PIPELINES render on
- * worker threads and invoke it from the worker of rank / pipeline 0 - a GUI host has to marshal it.  It may raise the
+/* Progress callback: fraction in [0,1], between passes (and between the parts of a very large call), at most every
+ * pt_config.progress_ms, and once with 1.0 when the frame is complete and in the output buffer.  pt_ctx_render invokes it
+ * on the calling thread; pt_render_multi and PT_FLAG_PIPELINES render on worker threads and invoke it from the worker of
+ * rank / pipeline 0 - a GUI host has to marshal it - except for the final 1.0, which comes from the calling thread after
+ * every rank / pipeline has finished.  It may raise the
  * cancel byte: the render then stops at that boundary.  It may call pt_ctx_snapshot on the context it was given to
  * (not under PT_FLAG_PIPELINES, where the accumulators live in child contexts: the snapshot reports an error). */
 typedef void (*pt_progress_fn)(void *user, float fraction);
@@ -142,6 +144,9 @@ typedef void (*pt_progress_fn)(void *user, float fraction);
 typedef struct pt_ctx pt_ctx;
 
 const char *pt_version(void);
+/* the back-end (-mllvm) switches the library was built with: the Makefile probes each against the compiler and drops the
+ * ones it rejects (they only steer instruction placement: same images with any subset) */
+const char *pt_build_flags(void);
 const char *pt_last_error(void);
 int pt_abi_version(void);
 int pt_device_count(void);
@@ -177,6 +182,17 @@ int pt_device_malloc(int device, size_t bytes, void **out);
 int pt_device_free(int device, void *p);
 int pt_device_download(int device, void *dst_host, const void *src_device, size_t bytes);
 
+/* Size limit of one scene's BVHs (pt_ctx_set_scene fails with PT_ERR_INVALID beyond it): the walkers pack a node index or a
+ * leaf code (first pair record << 2 | records - 1) into 26 bits of a queue entry - 2^26 nodes, 2^24 pair records (two
+ * triangles each) over all BVH meshes of the scene.  1 = fits. */
+int pt_bvh_refs_fit(uint64_t n_bvh_nodes, uint64_t n_pair_records);
+
+/* Device memory the wavefront backend may take for its ray queues in this context (bytes; 0 = the default: 85 % of what
+ * the device reports free, divided among the contexts one call creates on it, at most 36 GB).  The queues hold
+ * rays_per_pass primary rays at 352 B each; a pass that does not fit is halved until it does (a failed allocation does the
+ * same), which changes how the samples are batched and nothing in the image. */
+int pt_ctx_set_memory_budget(pt_ctx *ctx, size_t bytes);
+
 /* Enable HIP-event timing of every launch of the dominant kernel (fills pt_stats.ms_intersect). */
 int pt_ctx_set_profiling(pt_ctx *ctx, int enabled);
 /* Name of the kernel the wavefront backend launches for this context's scene with these pt_config.flags - the one
@@ -185,6 +201,18 @@ int pt_ctx_set_profiling(pt_ctx *ctx, int enabled);
  * walks), "k_pass" (every triangle tested per ray), "k_pass_bvh" (scan + depth-first parked walks: PT_CAND_BVH=0),
  * or "k_intersect" (separate kernels).  For profilers and bench.py; NULL without a scene. */
 const char *pt_ctx_pass_kernel(const pt_ctx *ctx, uint32_t flags);
+
+/* radiance(&ray, depth, &scene) (mod.rs:661-792) for ONE given ray, averaged over n_samples independent evaluations:
+ * what the reference's own test_radiance does (src/render/test.rs:146-183: the sum of 10 000 calls with depth 0 divided
+ * by their number), and the entry point through which hand-derived cases reach roulette / emission / specular / refract /
+ * Fresnel on the device (tests/kats_shading.py; `depth` 2 and 5 put the first hit behind mod.rs:760 and mod.rs:677).
+ * Sample i draws from the RNG stream (seed; counter = pixel, i, ...) exactly as sample i of framebuffer index `pixel`
+ * would - `pixel` is only that counter, no frame is involved - so the oracle's pto_radiance_mean_at with the same
+ * arguments walks the same paths.  depth < 12 (MAX_DEPTH, mod.rs:661).  backend / flags as in pt_config (PT_FLAG_PIPELINES
+ * is refused).  out_rgb = the mean, NOT clamped (the reference clamps in render_pixel, mod.rs:852-856, not in radiance);
+ * stats->ray_bounces = intersect_scene evaluations, exact.  Host pointers; blocking. */
+int pt_ctx_radiance(pt_ctx *ctx, const float o[3], const float d[3], uint32_t depth, uint32_t n_samples, uint64_t seed,
+                    uint32_t pixel, uint32_t backend, uint32_t flags, float out_rgb[3], pt_stats *stats);
 
 /* Single-ray queries through the same device intersection code (a6): the callers are object
  * picking / click-debug / orbit pivot (src/views/viewport_tab.rs:240-246, render_tab.rs:177-205).

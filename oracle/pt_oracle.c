@@ -523,6 +523,19 @@ void pto_radiance_mean(const pto_scene *s, const float o[3], const float d[3], u
     vst(out, vdivs(acc, (float)n));
 }
 
+/* the same with the `depth` argument of radiance() (mod.rs:662) free: hand-derived cases start behind the depth tests of
+ * mod.rs:677 (new_depth > 5) and mod.rs:760 (new_depth > 2) */
+void pto_radiance_mean_at(const pto_scene *s, const float o[3], const float d[3], uint32_t depth, uint64_t seed,
+                          uint32_t pixel, uint32_t n, float out[3], pto_counters *cnt) {
+    rctx c = {s, seed, pixel, 0, cnt, NULL, 0, 0, NULL};
+    v3 acc = V(0, 0, 0);
+    for (uint32_t i = 0; i < n; i++) {
+        c.sample = i;
+        acc = vadd(acc, radiance(&c, vld(o), vld(d), (int)depth, 1u));
+    }
+    vst(out, vdivs(acc, (float)n));
+}
+
 /* ------------------------------------------------------------------ render_pixel (mod.rs:794-857) */
 typedef struct {
     v3 pos, lens, su, sv;

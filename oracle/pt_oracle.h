@@ -54,6 +54,8 @@ void pto_intersect_batch(const pto_scene *s, const float *o, const float *d, uin
                          int32_t *object_id, int32_t *tri_id, float *x, float *nrm);
 void pto_radiance_mean(const pto_scene *s, const float o[3], const float d[3], uint64_t seed, uint32_t pixel,
                        uint32_t n, float out[3], pto_counters *cnt);
+void pto_radiance_mean_at(const pto_scene *s, const float o[3], const float d[3], uint32_t depth, uint64_t seed,
+                          uint32_t pixel, uint32_t n, float out[3], pto_counters *cnt);
 void pto_primary_ray(const pt_camera *cam, uint32_t width, uint32_t height, uint32_t pixel_index,
                      uint32_t sample, uint64_t seed, float o[3], float d[3]);
 void pto_render_pixel(const pto_scene *s, const pto_config *cfg, uint32_t pixel_index, float out[3],

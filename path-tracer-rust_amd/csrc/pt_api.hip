@@ -28,19 +28,26 @@ void set_error(const std::string &m) { g_last_error = m; }
         }                                                                                              \
     } while (0)
 
+// DevBuf::ensure's "out of device memory" (never leaves the library: render_wavefront retries with smaller passes and
+// reports PT_ERR_HIP when even the smallest does not fit)
+constexpr int PT_ERR_NOMEM_INTERNAL = -1000;
+
 template <class T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
-    int ensure(size_t count) {
+    size_t bytes() const { return p ? n * sizeof(T) : 0; }
+    int ensure(size_t count, bool tell_oom = false) {
         if (count <= n && p) return PT_OK;
         if (p) (void)hipFree(p);
         p = nullptr;
         n = 0;
         hipError_t e = hipMalloc((void **)&p, (count ? count : 1) * sizeof(T));
         if (e != hipSuccess) {
-            set_error(std::string("hipMalloc: ") + hipGetErrorString(e));
-            return PT_ERR_HIP;
+            p = nullptr;
+            (void)hipGetLastError();  // (the error is reported through the return value; do not leave it sticky)
+            set_error(std::string("hipMalloc of ") + std::to_string((count ? count : 1) * sizeof(T)) + " bytes: " + hipGetErrorString(e));
+            return (tell_oom && e == hipErrorOutOfMemory) ? PT_ERR_NOMEM_INTERNAL : PT_ERR_HIP;
         }
         n = count;
         return PT_OK;
@@ -144,6 +151,12 @@ struct pt_ctx {
     std::vector<pt_ctx *> pipes;
     std::vector<DevBuf<float>> pipe_out;
     bool borrowed_scene = false;
+    // memory-aware pass sizing: contexts that will hold ray queues on this device at the same time (pipelines of one call,
+    // ranks of pt_render_multi that share a device) and an explicit cap on the queue memory of this context (0 = 85 % of
+    // what hipMemGetInfo reports free, divided by `mem_share`)
+    uint32_t mem_share = 1;
+    size_t mem_budget = 0;
+    double cb_last_ms = 0.0;  // time of the last progress callback of the call in progress (throttle: pt_config.progress_ms)
 };
 
 namespace {
@@ -272,70 +285,108 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
     const uint64_t npix = F.npix;
     // 96 Mi primary rays per pass by default: 36 GB of ray queues (two containers x 4 slots per primary ray x 40 B) of the
     // 288 GB of HBM.  Fewer, longer launches: cornell 1024x768 @4096 spp 32 Mi 35.7, 48 Mi 35.7, 64 Mi 36.2, 96 Mi 36.4 G
-    // bounces/s (a launch ends with its slowest streams; 32 launches per frame instead of 98)
-    uint64_t want = cfg->rays_per_pass ? cfg->rays_per_pass : (96u << 20);
-    uint32_t spp_pass = (uint32_t)(want / npix);
-    if (spp_pass == 0) spp_pass = 1;
-    if (spp_pass > cfg->spp) spp_pass = cfg->spp;
-    if (spp_pass > kMaxPassSpp) spp_pass = kMaxPassSpp;  // sample-in-pass field of the stream bookkeeping word
-    // Streams: many more than the 2048 workgroups the chip holds at once, so that the dispatcher keeps every CU busy
-    // until a launch ends, but each still a few launches' worth of work for its workgroup - about 2048 primary rays
-    // per stream and pass (measured on cornell 1024x768: 2048 streams 22.0, 8192 24.3, 16384 24.7, 65536 23.2 G
-    // bounces/s).  A stream owns at most kMaxStreamPixels pixels (their accumulators live in LDS inside k_shade).
-    // (scenes with a BVH stage its nodes into LDS once per workgroup: twice the work per stream; mesh.json 2048 streams
-    // 7.3, 8192 7.6, 16384 7.0)
-    // (candidate scan, four waves per SIMD: 12288 streams 35.8, 16384 35.4, 8192 32.2, 24576 33.7 G bounces/s)
-    // (candidate scan with walks, mesh.json: 24576 streams 19.8, 26624 20.5, 28672 20.1, 30720 20.3, 32768 19.9 G bounces/s)
-    const uint64_t per_stream = c->scene.n_bvh_nodes != 0u ? (c->scene.cand_scan ? 3840u : 4096u) : (c->scene.cand_scan ? 2688u : 2048u);
-    uint64_t k_target = ((uint64_t)npix * spp_pass + per_stream - 1u) / per_stream;
-    if (k_target < 2048u) k_target = 2048u;
-    if (c->tune.streams) k_target = c->tune.streams;
-    uint32_t m = (uint32_t)((npix + k_target - 1) / k_target);
-    if (m == 0) m = 1;
-    if (m > kMaxStreamPixels) m = kMaxStreamPixels;
-    // A launch runs its workgroups in rounds of as many as the chip holds (four per CU); a stream's work grows with its m
-    // pixels, so a launch takes about ceil(K / resident) x m: among the m within -15 % / +20 % of the tuned size take the
-    // one for which that is smallest (cornell 1024x768: m = 21 -> 24, 37 450 streams in 36.6 rounds -> 32 768 in 32.0,
-    // 37.3 -> 37.7 G bounces/s).  Not for scenes with walks, whose streams differ too much in length for rounds to show
-    // (mesh.json: 24.0 rounds are slower than 25.6).
-    if (c->scene.cand_scan && c->scene.n_bvh_nodes == 0u && !c->tune.streams && c->n_cus != 0u && m >= 8u) {
-        const uint64_t resident = (uint64_t)c->n_cus * 4u;
-        uint32_t best_m = m;
-        uint64_t best_cost = ~0ull;
-        for (uint32_t mm = m - m * 15u / 100u; mm <= m + m / 5u && mm <= kMaxStreamPixels; ++mm) {
-            const uint64_t kk = (npix + mm - 1u) / mm;
-            const uint64_t cost = ((kk + resident - 1u) / resident) * mm;
-            if (cost < best_cost || (cost == best_cost && (mm > m ? mm - m : m - mm) < (best_m > m ? best_m - m : m - best_m))) {
-                best_cost = cost;
-                best_m = mm;
-            }
-        }
-        m = best_m;
-    }
-    const uint32_t K = (uint32_t)((npix + m - 1) / m);
-    // a primary ray has at most 4 descendants alive at one depth (two refract splits, mod.rs:760)
-    const uint64_t cap64 = (4ull * m * spp_pass + kBlock - 1) / kBlock * kBlock;
-    if (cap64 * K > 0xffffffffull / 2) {
-        set_error("rays per pass too large");
-        return PT_ERR_INVALID;
-    }
-    const uint32_t cap = (uint32_t)cap64;
-    const size_t slots = (size_t)K * cap;
-    for (int w = 0; w < 2; ++w) {
-        int rc;
-        if ((rc = c->q_od0[w].ensure(slots)) || (rc = c->q_od1[w].ensure(slots)) || (rc = c->q_tp[w].ensure(slots)))
-            return rc;
-    }
-    int rc;
-    // scenes without BVH meshes run a pass as one launch (k_pass), BVH scenes as k_pass_bvh unless their nodes are staged
-    // in LDS; PT_FLAG_SEPARATE_KERNELS / PT_PASS_KERNEL=0 / PT_PASS_BVH=0 keep the three-kernel form (A/B, profiling).
-    // Only that form needs the hit records: k_pass keeps hits in registers.
+    // bounces/s (a launch ends with its slowest streams; 32 launches per frame instead of 98).
+    // The default is what the DEVICE can give: 85 % of the free memory (plus what this context's queues hold already),
+    // divided by the contexts that share the device in this call (PT_FLAG_PIPELINES, ranks of pt_render_multi on one GPU),
+    // or pt_ctx_set_memory_budget's figure - at 352 B per primary ray (queues + hit records of the three-kernel form); and
+    // whatever was asked for, a failed allocation halves the pass and tries again: passes only change how the samples are
+    // batched, never the image.
     const bool bvh_ok = c->scene.n_bvh_nodes == 0u || (!(c->scene.bvh_in_lds & 1u) && c->tune.pass_bvh);
     const bool one_kernel = bvh_ok && c->tune.pass_kernel && !(cfg->flags & PT_FLAG_SEPARATE_KERNELS);
     const bool needs_hits = !one_kernel;
-    if ((needs_hits && (rc = c->hit.ensure(slots))) || (rc = c->cnt.ensure((size_t)kLevels * K)) || (rc = c->flags.ensure(1)) ||
-        (rc = c->blk_rays.ensure(K)) || (rc = c->acc.ensure(3 * (size_t)K * m)))
-        return rc;
+    uint64_t want = cfg->rays_per_pass;
+    if (!want) {
+        want = 96u << 20;
+        size_t held = c->hit.bytes();
+        for (int w = 0; w < 2; ++w) held += c->q_od0[w].bytes() + c->q_od1[w].bytes() + c->q_tp[w].bytes();
+        size_t avail = c->mem_budget;
+        if (!avail) {
+            size_t mem_free = 0, mem_total = 0;
+            if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess) avail = (size_t)((double)(mem_free + held) * 0.85) / (c->mem_share ? c->mem_share : 1u);
+        }
+        if (avail) {
+            const uint64_t fit = avail / 352u;
+            if (fit < want) want = fit;
+        }
+        if (c->mem_share > 1u && want > (96u << 20) / c->mem_share) want = (96u << 20) / c->mem_share;  // (co-resident contexts also share the chip)
+        if (want < npix) want = npix;  // one sample per pixel and pass at least
+    }
+    uint32_t spp_pass = 0, m = 0, K = 0, cap = 0;
+    for (;;) {
+        spp_pass = (uint32_t)(want / npix);
+        if (spp_pass == 0) spp_pass = 1;
+        if (spp_pass > cfg->spp) spp_pass = cfg->spp;
+        if (spp_pass > kMaxPassSpp) spp_pass = kMaxPassSpp;  // sample-in-pass field of the stream bookkeeping word
+        // Streams: many more than the 2048 workgroups the chip holds at once, so that the dispatcher keeps every CU busy
+        // until a launch ends, but each still a few launches' worth of work for its workgroup - about 2048 primary rays
+        // per stream and pass (measured on cornell 1024x768: 2048 streams 22.0, 8192 24.3, 16384 24.7, 65536 23.2 G
+        // bounces/s).  A stream owns at most kMaxStreamPixels pixels (their accumulators live in LDS inside k_shade).
+        // (scenes with a BVH stage its nodes into LDS once per workgroup: twice the work per stream; mesh.json 2048 streams
+        // 7.3, 8192 7.6, 16384 7.0)
+        // (candidate scan, four waves per SIMD: 12288 streams 35.8, 16384 35.4, 8192 32.2, 24576 33.7 G bounces/s)
+        // (candidate scan with walks, mesh.json: 24576 streams 19.8, 26624 20.5, 28672 20.1, 30720 20.3, 32768 19.9 G bounces/s)
+        const uint64_t per_stream = c->scene.n_bvh_nodes != 0u ? (c->scene.cand_scan ? 3840u : 4096u) : (c->scene.cand_scan ? 2688u : 2048u);
+        uint64_t k_target = ((uint64_t)npix * spp_pass + per_stream - 1u) / per_stream;
+        if (k_target < 2048u) k_target = 2048u;
+        if (c->tune.streams) k_target = c->tune.streams;
+        m = (uint32_t)((npix + k_target - 1) / k_target);
+        if (m == 0) m = 1;
+        if (m > kMaxStreamPixels) m = kMaxStreamPixels;
+        // A launch runs its workgroups in rounds of as many as the chip holds (four per CU); a stream's work grows with its m
+        // pixels, so a launch takes about ceil(K / resident) x m: among the m within -15 % / +20 % of the tuned size take the
+        // one for which that is smallest (cornell 1024x768: m = 21 -> 24, 37 450 streams in 36.6 rounds -> 32 768 in 32.0,
+        // 37.3 -> 37.7 G bounces/s).  Not for scenes with walks, whose streams differ too much in length for rounds to show
+        // (mesh.json: 24.0 rounds are slower than 25.6).
+        if (c->scene.cand_scan && c->scene.n_bvh_nodes == 0u && !c->tune.streams && c->n_cus != 0u && m >= 8u) {
+            const uint64_t resident = (uint64_t)c->n_cus * 4u;
+            uint32_t best_m = m;
+            uint64_t best_cost = ~0ull;
+            for (uint32_t mm = m - m * 15u / 100u; mm <= m + m / 5u && mm <= kMaxStreamPixels; ++mm) {
+                const uint64_t kk = (npix + mm - 1u) / mm;
+                const uint64_t cost = ((kk + resident - 1u) / resident) * mm;
+                if (cost < best_cost || (cost == best_cost && (mm > m ? mm - m : m - mm) < (best_m > m ? best_m - m : m - best_m))) {
+                    best_cost = cost;
+                    best_m = mm;
+                }
+            }
+            m = best_m;
+        }
+        K = (uint32_t)((npix + m - 1) / m);
+        // a primary ray has at most 4 descendants alive at one depth (two refract splits, mod.rs:760)
+        const uint64_t cap64 = (4ull * m * spp_pass + kBlock - 1) / kBlock * kBlock;
+        if (cap64 * K > 0xffffffffull / 2) {
+            if (spp_pass > 1u && !cfg->rays_per_pass) {  // (a default this large only on a device with > 680 GB)
+                want /= 2;
+                continue;
+            }
+            set_error("rays per pass too large");
+            return PT_ERR_INVALID;
+        }
+        cap = (uint32_t)cap64;
+        const size_t slots = (size_t)K * cap;
+        int rc = PT_OK;
+        for (int w = 0; w < 2 && !rc; ++w)
+            if ((rc = c->q_od0[w].ensure(slots, true)) || (rc = c->q_od1[w].ensure(slots, true)) || (rc = c->q_tp[w].ensure(slots, true))) break;
+        // scenes without BVH meshes run a pass as one launch (k_pass), BVH scenes as k_pass_bvh unless their nodes are staged
+        // in LDS; PT_FLAG_SEPARATE_KERNELS / PT_PASS_KERNEL=0 / PT_PASS_BVH=0 keep the three-kernel form (A/B, profiling).
+        // Only that form needs the hit records: k_pass keeps hits in registers.
+        if (!rc && needs_hits) rc = c->hit.ensure(slots, true);
+        if (!rc) rc = c->cnt.ensure((size_t)kLevels * K, true);
+        if (!rc) rc = c->flags.ensure(1, true);
+        if (!rc) rc = c->blk_rays.ensure(K, true);
+        if (!rc) rc = c->acc.ensure(3 * (size_t)K * m, true);
+        if (!rc) break;
+        if (rc != PT_ERR_NOMEM_INTERNAL) return rc;
+        // out of device memory: give back what this attempt took and try passes of half the size
+        for (int w = 0; w < 2; ++w) {
+            c->q_od0[w].release();
+            c->q_od1[w].release();
+            c->q_tp[w].release();
+        }
+        c->hit.release();
+        if (spp_pass <= 1u) return PT_ERR_HIP;  // (the message names the allocation that failed)
+        want = (uint64_t)npix * (spp_pass / 2u ? spp_pass / 2u : 1u);
+    }
     c->K = K;
     c->cap = cap;
     F.n_streams = K;  // stream b owns pixels b, b+K, ...; accumulators are stream-major (K*m slots per channel)
@@ -364,7 +415,7 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
     // the callback is throttled to pt_config.progress_ms (0 = 500 ms, PT_PROGRESS_EVERY_PASS = every pass boundary);
     // the cancel byte is read at EVERY pass boundary (the reference polls it every 100 ms, mod.rs:947-958).
     const double cb_every_ms = cfg->progress_ms == PT_PROGRESS_EVERY_PASS ? 0.0 : (cfg->progress_ms ? (double)cfg->progress_ms : 500.0);
-    double cb_last_ms = now_ms();
+    double &cb_last_ms = c->cb_last_ms;  // (set when the call began: pt_ctx_render; a call rendered in parts keeps one clock)
     for (uint32_t p = 0; p < n_pass; ++p) {
         if (p >= 2) HIP_TRY(hipEventSynchronize(pass_done[p & 1]));  // keep two passes in flight
         if (cancel && *cancel) {
@@ -398,9 +449,9 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
             if (c->scene.n_bvh_nodes != 0u && !c->scene.cand_scan)
                 launch_pass_bvh(st, K, c->scene, F, queue_of(c, 0), queue_of(c, 1), cap, s0, s_here, m, c->acc.p,
                                 c->blk_rays.p, c->flags.p);
-            else
-                launch_pass(st, K, c->scene, F, queue_of(c, 0), queue_of(c, 1), cap, s0, s_here, m, c->acc.p,
-                            c->blk_rays.p, c->flags.p);
+            else if (launch_pass(st, K, c->scene, F, queue_of(c, 0), queue_of(c, 1), cap, s0, s_here, m, c->acc.p, c->blk_rays.p,
+                                 c->flags.p) != hipSuccess)
+                return PT_ERR_HIP;  // (the message says how much LDS the scene's kernel asked for)
             if (c->profiling) {
                 HIP_TRY(hipEventRecord(b, st));
                 ++n_prof;
@@ -508,7 +559,7 @@ int render_mega(pt_ctx *c, const pt_config *cfg, const FrameParams &F, hipStream
     }
     HIP_TRY(hipEventRecord(ev_begin, st));
     const double cb_every_ms = cfg->progress_ms == PT_PROGRESS_EVERY_PASS ? 0.0 : (cfg->progress_ms ? (double)cfg->progress_ms : 500.0);
-    double cb_last_ms = now_ms();
+    double &cb_last_ms = c->cb_last_ms;  // (set when the call began: pt_ctx_render; a call rendered in parts keeps one clock)
     bool cancelled = false;
     uint32_t rounds_done = 0;
     uint64_t samples = 0;
@@ -570,7 +621,11 @@ int render_mega(pt_ctx *c, const pt_config *cfg, const FrameParams &F, hipStream
 
 extern "C" {
 
-const char *pt_version(void) { return "ptrace-hip 0.1 (gfx950)"; }
+const char *pt_version(void) { return "ptrace-hip 0.3 (gfx950)"; }
+#ifndef PT_BUILD_FLAGS
+#define PT_BUILD_FLAGS ""
+#endif
+const char *pt_build_flags(void) { return PT_BUILD_FLAGS; }
 const char *pt_last_error(void) { return g_last_error.c_str(); }
 int pt_abi_version(void) { return PT_ABI_VERSION; }
 int pt_device_count(void) { return device_count_quiet(); }
@@ -831,6 +886,17 @@ const char *pt_ctx_pass_kernel(const pt_ctx *c, uint32_t flags) {
     return n_nodes != 0u ? "k_pass_bvh" : "k_pass";
 }
 
+int pt_bvh_refs_fit(uint64_t n_bvh_nodes, uint64_t n_pair_records) { return host::bvh_refs_fit(n_bvh_nodes, n_pair_records) ? 1 : 0; }
+
+int pt_ctx_set_memory_budget(pt_ctx *c, size_t bytes) {
+    if (!c) {
+        set_error("ctx is NULL");
+        return PT_ERR_INVALID;
+    }
+    c->mem_budget = bytes;
+    return PT_OK;
+}
+
 int pt_ctx_set_profiling(pt_ctx *c, int enabled) {
     if (!c) {
         set_error("ctx is NULL");
@@ -839,6 +905,17 @@ int pt_ctx_set_profiling(pt_ctx *c, int enabled) {
     c->profiling = enabled != 0;
     return PT_OK;
 }
+
+// progress relay for pipeline 0 / rank 0 of a call that renders on several contexts: its fractions are passed on, its
+// "1.0" is not - the call is complete when EVERY pipeline has finished and the frame is assembled, and the parent says so
+struct Below1 {
+    pt_progress_fn cb;
+    void *user;
+    static void fn(void *self, float f) {
+        Below1 *r = (Below1 *)self;
+        if (f < 1.0f) r->cb(r->user, f);
+    }
+};
 
 // n concurrent wavefront pipelines over the pixels of one call (PT_FLAG_PIPELINES)
 static int render_pipelined(pt_ctx *c, const pt_config *cfg, uint32_t n, uint32_t ib, uint32_t ie, float *d_out,
@@ -868,6 +945,8 @@ static int render_pipelined(pt_ctx *c, const pt_config *cfg, uint32_t n, uint32_
         p->cand_ok = c->cand_ok;
         p->has_scene = true;
         p->profiling = c->profiling;
+        p->mem_share = n;  // n sets of ray queues on this device at once
+        p->mem_budget = c->mem_budget / n;
         cfgs[j].flags &= ~PT_FLAG_PIPELINES(15);
         cfgs[j].idx_begin = ib;
         cfgs[j].idx_end = ie;
@@ -879,11 +958,12 @@ static int render_pipelined(pt_ctx *c, const pt_config *cfg, uint32_t n, uint32_
         if (rc) return rc;
     }
     std::vector<std::thread> th;
+    Below1 relay{cb, user};
     for (uint32_t j = 0; j < n; ++j) {
         if (own[j] == 0u) continue;
         th.emplace_back([&, j]() {
-            rcs[j] = pt_ctx_render(c->pipes[j], &cfgs[j], c->pipe_out[j].p, nullptr, cancel, j == 0 ? cb : nullptr, user,
-                                   &sts[j]);
+            rcs[j] = pt_ctx_render(c->pipes[j], &cfgs[j], c->pipe_out[j].p, nullptr, cancel, (j == 0 && cb) ? &Below1::fn : nullptr,
+                                   &relay, &sts[j]);
             if (rcs[j] != PT_OK) errs[j] = g_last_error;
         });
     }
@@ -943,7 +1023,8 @@ int pt_ctx_render(pt_ctx *c, const pt_config *cfg, void *d_out_rgb, void *hip_st
         c->scene.planar = (cfg->flags & PT_FLAG_NO_BVH) ? 0u : 1u;
         rc = render_pipelined(c, cfg, n_pipes, ib, ie, (float *)d_out_rgb, cancel, cb, user, stats);
         c->scene.n_bvh_nodes = c->n_bvh_nodes;
-    c->scene.planar = 1u;
+        c->scene.planar = 1u;
+        if (cb && rc == PT_OK) cb(user, 1.0f);  // every pipeline has finished and the chunks are in place
         if (stats) stats->ms_total = now_ms() - t0p;
         return rc;
     }
@@ -979,8 +1060,19 @@ int pt_ctx_render(pt_ctx *c, const pt_config *cfg, void *d_out_rgb, void *hip_st
     c->live_out = (float *)d_out_rgb;
     c->live_total = total;
     c->live_stream = st;
+    c->cb_last_ms = now_ms();
+    const double cb_every_ms = cfg->progress_ms == PT_PROGRESS_EVERY_PASS ? 0.0 : (cfg->progress_ms ? (double)cfg->progress_ms : 500.0);
     rc = PT_OK;
     for (uint32_t part = 0; part < n_parts && rc == PT_OK; ++part) {
+        // a part boundary is a progress point of its own (a part of one or two passes makes no callback from inside); a cancel
+        // raised there is seen by the part's first pass, which leaves it and the parts behind it black
+        if (cb && part > 0u) {
+            const double t_now = now_ms();
+            if (t_now - c->cb_last_ms >= cb_every_ms) {
+                c->cb_last_ms = t_now;
+                cb(user, (float)part / (float)n_parts);
+            }
+        }
         FrameParams Fp = F;
         Fp.k_begin = part * part_px;
         Fp.npix = (total - Fp.k_begin) < part_px ? (total - Fp.k_begin) : part_px;
@@ -1031,6 +1123,73 @@ int pt_ctx_render(pt_ctx *c, const pt_config *cfg, void *d_out_rgb, void *hip_st
     c->live_npix = 0;
     c->live_out = nullptr;
     return rc;
+}
+
+int pt_ctx_radiance(pt_ctx *c, const float o[3], const float d[3], uint32_t depth, uint32_t n_samples, uint64_t seed,
+                    uint32_t pixel, uint32_t backend, uint32_t flags, float out_rgb[3], pt_stats *stats) {
+    if (!c || !o || !d || !out_rgb) {
+        set_error("NULL argument");
+        return PT_ERR_INVALID;
+    }
+    if (!c->has_scene) {
+        set_error("no scene set");
+        return PT_ERR_INVALID;
+    }
+    if (n_samples == 0u || n_samples > (1u << 24) || depth >= (uint32_t)kMaxDepth ||
+        (backend != PT_BACKEND_WAVEFRONT && backend != PT_BACKEND_MEGAKERNEL) || ((flags >> 8) & 15u) > 1u) {
+        set_error("n_samples outside 1..2^24, depth >= MAX_DEPTH, unknown backend, or PT_FLAG_PIPELINES (not offered for a one-ray call)");
+        return PT_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    // a frame of ONE pixel whose samples all start with the given ray: the pixel index is only the RNG counter
+    pt_config cfg{};
+    cfg.width = 1;
+    cfg.height = 1;
+    cfg.spp = n_samples;
+    cfg.backend = backend;
+    cfg.seed = seed;
+    cfg.flags = flags;
+    FrameParams F = make_frame(c, &cfg, 0u, 1u);
+    F.idx_begin = pixel;
+    F.npix = 1;
+    F.probe = 1u;
+    F.depth0 = depth;
+    F.probe_ox = o[0];
+    F.probe_oy = o[1];
+    F.probe_oz = o[2];
+    F.probe_dx = d[0];
+    F.probe_dy = d[1];
+    F.probe_dz = d[2];
+    if (stats) memset(stats, 0, sizeof *stats);
+    c->scene.n_bvh_nodes = (flags & PT_FLAG_NO_BVH) ? 0u : c->n_bvh_nodes;
+    c->scene.planar = (flags & PT_FLAG_NO_BVH) ? 0u : 1u;
+    c->scene.cand_scan = cand_scan_for(c, flags);
+    const double t0 = now_ms();
+    pt_stats ps;
+    memset(&ps, 0, sizeof ps);
+    hipStream_t st = c->stream;
+    int rc = backend == PT_BACKEND_WAVEFRONT ? render_wavefront(c, &cfg, F, st, nullptr, nullptr, nullptr, &ps)
+                                             : render_mega(c, &cfg, F, st, nullptr, nullptr, nullptr, &ps);
+    c->scene.n_bvh_nodes = c->n_bvh_nodes;
+    c->scene.planar = 1u;
+    c->scene.cand_scan = cand_scan_for(c, 0u);
+    if (rc != PT_OK) return rc;
+    DevBuf<float> d_out;
+    if ((rc = d_out.ensure(3))) return rc;
+    launch_resolve(st, c->acc.p, d_out.p, 1u, n_samples, c->live_streams, c->live_m, false);  // the mean, not clamped
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipMemcpy(out_rgb, d_out.p, 3 * sizeof(float), hipMemcpyDeviceToHost);
+    d_out.release();
+    if (e != hipSuccess) {
+        set_error(std::string("pt_ctx_radiance: ") + hipGetErrorString(e));
+        return PT_ERR_HIP;
+    }
+    if (stats) {
+        *stats = ps;
+        stats->ms_total = now_ms() - t0;
+    }
+    return PT_OK;
 }
 
 int pt_ctx_intersect(pt_ctx *c, const float *o, const float *d, uint32_t n, float *t, int32_t *object_id,
@@ -1246,7 +1405,7 @@ int pt_ctx_numerics_sweep(pt_ctx *c, uint64_t out[4]) {
 static int render_band_to_host(int dev, const pt_config *cfg, const pt_camera *cam, const pt_object *objs,
                                uint32_t n_objs, const pt_triangle *tris, uint32_t n_tris, float *out_rgb,
                                const volatile uint8_t *cancel, pt_progress_fn cb, void *user, pt_stats *stats,
-                               std::string *err) {
+                               std::string *err, uint32_t mem_share = 1) {
     uint32_t ib = 0, ie = 0;
     int rc = check_cfg(cfg, &ib, &ie);
     if (stats) memset(stats, 0, sizeof *stats);
@@ -1254,6 +1413,7 @@ static int render_band_to_host(int dev, const pt_config *cfg, const pt_camera *c
     if (!rc && own == 0u) return PT_OK;  // this rank owns no chunk of the band: nothing was created yet
     pt_ctx *c = nullptr;
     if (!rc) rc = pt_ctx_create(dev, &c);
+    if (!rc) c->mem_share = mem_share;
     if (!rc) rc = pt_ctx_set_scene(c, cam, objs, n_objs, tris, n_tris);
     float *d_out = nullptr;
     const size_t nfl = (size_t)own * 3;
@@ -1329,6 +1489,7 @@ int pt_render_multi(const pt_config *cfg, uint32_t n_ranks, const pt_camera *cam
     std::vector<std::string> errs(n_ranks);
     std::vector<std::thread> th;
     const double t0 = now_ms();
+    Below1 relay{cb, user};
     for (uint32_t r = 0; r < n_ranks; ++r) {
         cfgs[r].idx_begin = ib;
         cfgs[r].idx_end = ie;
@@ -1338,9 +1499,12 @@ int pt_render_multi(const pt_config *cfg, uint32_t n_ranks, const pt_camera *cam
             cfgs[r].chunk_step = n_ranks;
         }
         if (owned_pixels(&cfgs[r], ib, ie) == 0u) continue;  // more ranks than chunks
-        th.emplace_back([&, r]() {
-            rcs[r] = render_band_to_host((int)(r % (uint32_t)n_dev), &cfgs[r], cam, objs, n_objs, tris, n_tris, out_rgb,
-                                         cancel, r == 0 ? cb : nullptr, user, &sts[r], &errs[r]);
+        // ranks r, r + n_dev, ... share device r % n_dev: each takes its share of that device's memory for its ray queues
+        const uint32_t dev = r % (uint32_t)n_dev;
+        const uint32_t on_dev = (n_ranks - dev + (uint32_t)n_dev - 1u) / (uint32_t)n_dev;
+        th.emplace_back([&, r, dev, on_dev]() {
+            rcs[r] = render_band_to_host((int)dev, &cfgs[r], cam, objs, n_objs, tris, n_tris, out_rgb, cancel,
+                                         (r == 0 && cb) ? &Below1::fn : nullptr, &relay, &sts[r], &errs[r], on_dev);
         });
     }
     for (auto &t : th) t.join();
@@ -1362,6 +1526,7 @@ int pt_render_multi(const pt_config *cfg, uint32_t n_ranks, const pt_camera *cam
             set_error("rank " + std::to_string(r) + ": " + errs[r]);
             return rcs[r];
         }
+    if (cb) cb(user, 1.0f);  // every rank has finished and its rows are in out_rgb
     return PT_OK;
 }
 

@@ -269,6 +269,11 @@ struct FrameParams {
     uint32_t n_streams;            // wavefront: K ray streams; stream b owns the call's pixels b, b+K, b+2K, ...
     uint32_t k_begin;              // first call-local pixel of this launch's part of the call (large calls are rendered in
                                    // parts of about a million pixels: pt_ctx_render); npix counts the part's pixels
+    uint32_t depth0;               // `depth` argument of the radiance() calls the primary rays stand for: 0 for a frame (mod.rs:844)
+    // pt_ctx_radiance: every "primary ray" of the call is this one ray (radiance(&ray, depth0, scene), test.rs:146-183); the
+    // call has one pixel, whose index idx_begin is only the RNG counter, and spp samples
+    uint32_t probe;
+    float probe_ox, probe_oy, probe_oz, probe_dx, probe_dy, probe_dz;
 };
 
 // framebuffer index of the k-th pixel of this call (identity + idx_begin for a contiguous band)
@@ -1677,6 +1682,15 @@ __device__ __forceinline__ void shade_surface(const Params &F, const PathRay &in
 
 // render_pixel's per-sample ray (mod.rs:805-843) for framebuffer index `pix`, sample `s`
 __device__ __forceinline__ PathRay primary_ray(const FrameParams &F, uint32_t pix, uint32_t s) {
+    if (F.probe) {  // wave-uniform (a kernel argument): pt_ctx_radiance's fixed ray, sample s of "pixel" pix
+        PathRay r;
+        r.o = mk(F.probe_ox, F.probe_oy, F.probe_oz);
+        r.d = mk(F.probe_dx, F.probe_dy, F.probe_dz);
+        r.thr = mk(1.0f, 1.0f, 1.0f);
+        r.pix = pix;
+        r.meta = pack_meta(s, F.depth0, 1u);
+        return r;
+    }
     const uint32_t y = F.height - 1u - pix / F.width;
     const uint32_t x = pix % F.width;
     const float ysub = (float)((s / 2u) % 2u);
@@ -1695,7 +1709,7 @@ __device__ __forceinline__ PathRay primary_ray(const FrameParams &F, uint32_t pi
     r.d = normalize(lens - sensor_pos);
     r.thr = mk(1.0f, 1.0f, 1.0f);
     r.pix = pix;
-    r.meta = pack_meta(s, 0u, 1u);
+    r.meta = pack_meta(s, F.depth0, 1u);
     return r;
 }
 

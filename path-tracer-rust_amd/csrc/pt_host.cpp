@@ -214,6 +214,12 @@ struct BvhBuilder {
 
 }  // namespace
 
+// The per-wave walk queue (bvh_closest_queue) and the leaf list (bvh_closest_postponed) pack `owner lane | reference << 6`
+// into 32 bits: a node index, or a leaf code first_record << kBvhLeafBits | count - 1, has 26 bits.
+bool bvh_refs_fit(uint64_t n_nodes, uint64_t n_pair_records) {
+    return n_nodes < (1ull << 26) && (n_pair_records << kBvhLeafBits) < (1ull << 26);
+}
+
 bool flatten_scene(const pt_camera &cam, const pt_object *objs, uint32_t n_objs, const pt_triangle *tris,
                    uint32_t n_tris, FlatScene &out, std::string &err) {
     if (n_objs >= (1u << 30) || n_tris >= (1u << 30)) {
@@ -370,6 +376,11 @@ bool flatten_scene(const pt_camera &cam, const pt_object *objs, uint32_t n_objs,
                 if (!have_bvh) out.bvh_pair_base = (uint32_t)pairs_mark;
                 have_bvh = true;
                 out.bvh_pair_span = (uint32_t)out.tri_pairs.size() - out.bvh_pair_base;
+                if (!bvh_refs_fit(out.bvh_nodes.size(), out.tri_pairs.size())) {
+                    err = "mesh too large for the BVH walkers: node indices and leaf codes are packed into 26 bits of a queue entry "
+                          "(2^26 nodes, 2^24 pair records with leaves of 3-4 records)";
+                    return false;
+                }
             } else {
                 for (size_t k = 0; k < bt.size(); k += 2) {  // list order, two triangles per record
                     TriPairRec rec{};

@@ -46,6 +46,7 @@ void mesh_bounding_box(const pt_triangle *tris, uint32_t n, pt_triangle out[12])
 void box_pair_records(const pt_triangle box[12], const float position[3], TriPairRec out[6]);
 // validate + flatten (see pt_device.h for the record layouts); false + message on malformed input
 // `cam` only widens the distance bound that sizes the BVH box padding (ray origins include the lens centre)
+bool bvh_refs_fit(uint64_t n_nodes, uint64_t n_pair_records);
 bool flatten_scene(const pt_camera &cam, const pt_object *objs, uint32_t n_objs, const pt_triangle *tris,
                    uint32_t n_tris, FlatScene &out, std::string &err);
 

@@ -20,7 +20,7 @@ struct RayQueue {
 };
 
 // one whole pass of a scene without BVH meshes in one launch (see k_pass)
-void launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const FrameParams &F, const RayQueue &q0,
+hipError_t launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const FrameParams &F, const RayQueue &q0,
                  const RayQueue &q1, uint32_t cap, uint32_t s0, uint32_t s_here, uint32_t m, unsigned long long *acc,
                  unsigned long long *blk_rays, uint32_t *flags);
 // the same for scenes with BVH meshes (nodes read from global memory: DevScene.bvh_in_lds bit 0 clear)
@@ -38,7 +38,7 @@ void launch_scatter_chunks(hipStream_t st, const float *src, float *dst, uint32_
                            uint32_t j);
 // acc is stream-major: pixel p = slot (p % n_streams) * m + p / n_streams of each colour plane (megakernel: 1, npix)
 void launch_resolve(hipStream_t st, const unsigned long long *acc, float *out, uint32_t npix, uint32_t spp,
-                    uint32_t n_streams, uint32_t m);
+                    uint32_t n_streams, uint32_t m, bool clamp = true);
 // one round of the megakernel: samples [s_begin, s_end) of every pixel, n_split lanes of lane_spp samples per pixel
 void launch_mega(hipStream_t st, uint32_t grid, const DevScene &S, const FrameParams &F, unsigned long long *acc,
                  uint32_t s_begin, uint32_t s_end, uint32_t lane_spp, uint32_t n_split, unsigned long long *total_rays);

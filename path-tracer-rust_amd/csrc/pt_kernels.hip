@@ -27,9 +27,13 @@
 // Queue arrays (per ray): od0 = (ox,oy,oz,dx) 16 B, od1 = (dy,dz) 8 B, tp = (throughput rgb, bookkeeping word) 16 B;
 // hit = (t, id) 8 B (three-kernel form only).  k_pass moves 40 B out + 40 B in per ray of depth >= 1; the separate
 // kernels 32 B/ray (intersect) and 48 B in + 40 B out per survivor (shade).
+#include <string>
+
 #include "pt_kernels.h"
 
 namespace pt {
+
+void set_error(const std::string &m);  // pt_api.hip
 
 // dynamic LDS of the kernels that intersect: staged BVH nodes + per-lane traversal stacks (0 bytes for scenes
 // without a BVH mesh).  No static __shared__ object precedes it in those kernels, so its base is 16-byte aligned.
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams F, RayQueue q, 
         const uint32_t pl = stream_pixel(F.n_streams, b, g % mb);
         const uint32_t s = s0 + g / mb;
         const PathRay r = primary_ray(F, global_pixel(F, pl), s);
-        store_ray(q, base + g, r.o, r.d, r.thr, pack_word(g % mb, g / mb, 0u, 1u));
+        store_ray(q, base + g, r.o, r.d, r.thr, pack_word(g % mb, g / mb, F.depth0, 1u));
     }
     if (tid == 0) cnt0[b] = n;
 }
@@ -422,7 +426,7 @@ __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, R
                 if (depth == 0u) {  // render_pixel's ray for (pixel i % mb of the stream, sample s0 + i / mb)
                     const uint32_t pj = i % mb, sj = i / mb;
                     in = primary_ray(F, lds_pix[pj], s0 + sj);
-                    word = pack_word(pj, sj, 0u, 1u);
+                    word = pack_word(pj, sj, F.depth0, 1u);
                 } else {
                     const float4 a = *reinterpret_cast<const float4 *>(qin.od0 + i * 16u);
                     const float4 tp = *reinterpret_cast<const float4 *>(qin.tp + i * 16u);
@@ -677,7 +681,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
             if (level == 0u) {
                 const uint32_t pj = i % mb, sj = i / mb;
                 in = primary_ray(F, lds_pix[pj], s0 + sj);
-                word = pack_word(pj, sj, 0u, 1u);
+                word = pack_word(pj, sj, F.depth0, 1u);
             } else {
                 load_ray_slice(qin, i, in.o, in.d, in.thr, word);
             }
@@ -735,7 +739,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
                     if (depth == 0u) {  // render_pixel's ray for (pixel i % mb of the stream, sample s0 + i / mb)
                         const uint32_t pj = i % mb, sj = i / mb;
                         in = primary_ray(F, lds_pix[pj], s0 + sj);
-                        word = pack_word(pj, sj, 0u, 1u);
+                        word = pack_word(pj, sj, F.depth0, 1u);
                     } else {
                         load_ray_slice(qin, i, in.o, in.d, in.thr, word);
                     }
@@ -938,7 +942,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_bvh(DevScene S, FrameParams 
     for (uint32_t g = tid; g < n; g += kBlock) {  // level 0: render_pixel's rays (pixel g % mb, sample s0 + g / mb)
         const uint32_t pj = g % mb, sj = g / mb;
         const PathRay r = primary_ray(F, lds_pix[pj], s0 + sj);
-        store_ray(q0, base + g, r.o, r.d, r.thr, pack_word(pj, sj, 0u, 1u));
+        store_ray(q0, base + g, r.o, r.d, r.thr, pack_word(pj, sj, F.depth0, 1u));
     }
     uint32_t n_park = 0;  // wave-uniform
     StreamSlice qin{}, qout{};
@@ -1065,7 +1069,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_bvh(DevScene S, FrameParams 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_resolve(const unsigned long long *__restrict__ acc,
                                                     float *__restrict__ out, uint32_t npix, uint32_t spp,
-                                                    uint32_t n_streams, uint32_t m) {
+                                                    uint32_t n_streams, uint32_t m, uint32_t clamp) {
     const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= npix) return;
     // pixel p is pixel j = p / K of stream b = p % K; its accumulator is slot b*m + j (megakernel: K = 1, m = npix)
@@ -1075,7 +1079,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const unsigned long long *__
     for (int c = 0; c < 3; ++c) {
         const double sum = (double)acc[(size_t)c * plane + slot] * (1.0 / 4294967296.0);
         const float v = (float)sum / (float)spp;  // radiance_v / samples_per_pixel, mod.rs:849
-        out[(size_t)p * 3 + c] = clamp01(v);      // mod.rs:852-856
+        out[(size_t)p * 3 + c] = clamp ? clamp01(v) : v;  // mod.rs:852-856 (pt_ctx_radiance: the mean itself)
     }
 }
 
@@ -1408,9 +1412,9 @@ void launch_shade(hipStream_t st, uint32_t K, const DevScene &S, const FramePara
     hipLaunchKernelGGL(k_shade, dim3(K), dim3(kBlock), lds, st, S, P, qin, qout, hit, cnt_in, cnt_out, cap, acc,
                        flags, m);
 }
-void launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const FrameParams &F, const RayQueue &q0,
-                 const RayQueue &q1, uint32_t cap, uint32_t s0, uint32_t s_here, uint32_t m, unsigned long long *acc,
-                 unsigned long long *blk_rays, uint32_t *flags) {
+hipError_t launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const FrameParams &F, const RayQueue &q0,
+                       const RayQueue &q1, uint32_t cap, uint32_t s0, uint32_t s_here, uint32_t m, unsigned long long *acc,
+                       unsigned long long *blk_rays, uint32_t *flags) {
     // The deferral buffers are 24 KB per workgroup: worth it while 5-6 workgroups still fit a CU's 160 KB of LDS (the
     // accumulators of a stream take 28 B per pixel); frames so large that a stream owns hundreds of pixels (4096^2:
     // 1024) shade every material in place instead.
@@ -1443,9 +1447,15 @@ void launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const FrameParam
         // (more than 64 KB of dynamic LDS - wide deep trees with hundreds of pixels per stream - has to be asked for)
 #define PT_LAUNCH_CAND(ST, DF, BV)                                                                                     \
     do {                                                                                                               \
-        if (lds > 64u * 1024u)                                                                                         \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pass_cand<ST, DF, BV>),                         \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
+        if (lds > 64u * 1024u) {                                                                                       \
+            const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pass_cand<ST, DF, BV>),         \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+            if (ea != hipSuccess) {                                                                                    \
+                set_error("k_pass_cand needs " + std::to_string(lds) + " bytes of LDS per workgroup for this scene: " +  \
+                          hipGetErrorString(ea));                                                                      \
+                return ea;                                                                                             \
+            }                                                                                                          \
+        }                                                                                                              \
         hipLaunchKernelGGL((k_pass_cand<ST, DF, BV>), dim3(K), dim3(kBlock), lds, st, S2, F, q0, q1, cap, s0, s_here, m, acc, blk_rays, flags); \
     } while (0)
         if (bvh && staged)
@@ -1461,7 +1471,7 @@ void launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const FrameParam
         else
             PT_LAUNCH_CAND(false, false, false);
 #undef PT_LAUNCH_CAND
-        return;
+        return hipSuccess;
     }
     if (lds_defer <= 32u * 1024u)
         hipLaunchKernelGGL(k_pass<true>, dim3(K), dim3(kBlock), lds_defer, st, S, F, q0, q1, cap, s0, s_here, m, acc,
@@ -1469,6 +1479,7 @@ void launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const FrameParam
     else
         hipLaunchKernelGGL(k_pass<false>, dim3(K), dim3(kBlock), lds_plain, st, S, F, q0, q1, cap, s0, s_here, m, acc,
                            blk_rays, flags);
+    return hipSuccess;
 }
 void launch_pass_bvh(hipStream_t st, uint32_t K, const DevScene &S, const FrameParams &F, const RayQueue &q0,
                      const RayQueue &q1, uint32_t cap, uint32_t s0, uint32_t s_here, uint32_t m, unsigned long long *acc,
@@ -1481,9 +1492,9 @@ void launch_scatter_chunks(hipStream_t st, const float *src, float *dst, uint32_
     hipLaunchKernelGGL(k_scatter_chunks, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, st, src, dst, npix, C, n, j);
 }
 void launch_resolve(hipStream_t st, const unsigned long long *acc, float *out, uint32_t npix, uint32_t spp,
-                    uint32_t n_streams, uint32_t m) {
+                    uint32_t n_streams, uint32_t m, bool clamp) {
     hipLaunchKernelGGL(k_resolve, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, st, acc, out, npix, spp,
-                       n_streams, m);
+                       n_streams, m, clamp ? 1u : 0u);
 }
 void launch_mega(hipStream_t st, uint32_t grid, const DevScene &S, const FrameParams &F, unsigned long long *acc,
                  uint32_t s_begin, uint32_t s_end, uint32_t lane_spp, uint32_t n_split, unsigned long long *total_rays) {

@@ -112,6 +112,8 @@ def oracle():
     L.pto_intersect_batch.argtypes = [C.POINTER(PtoScene), fp, fp, C.c_uint32, fp, i32p, i32p, fp, fp]
     L.pto_radiance_mean.argtypes = [C.POINTER(PtoScene), fp, fp, C.c_uint64, C.c_uint32, C.c_uint32, fp,
                                     C.POINTER(PtoCounters)]
+    L.pto_radiance_mean_at.argtypes = [C.POINTER(PtoScene), fp, fp, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, fp,
+                                       C.POINTER(PtoCounters)]
     L.pto_primary_ray.argtypes = [C.POINTER(PtCamera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                   C.c_uint64, fp, fp]
     L.pto_render_pixel.argtypes = [C.POINTER(PtoScene), C.POINTER(PtoConfig), C.c_uint32, fp,
@@ -172,6 +174,7 @@ def product():
     L.pt_ctx_render.argtypes = [C.c_void_p, C.POINTER(PtConfig), C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.POINTER(PtStats)]
     L.pt_ctx_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.pt_ctx_set_memory_budget.argtypes = [C.c_void_p, C.c_size_t]
     L.pt_ctx_pass_kernel.argtypes = [C.c_void_p, C.c_uint32]
     L.pt_ctx_pass_kernel.restype = C.c_char_p
     L.pt_render_multi.argtypes = [C.POINTER(PtConfig), C.c_uint32, C.POINTER(PtCamera), C.POINTER(PtObject), C.c_uint32,
@@ -188,6 +191,9 @@ def product():
     L.pt_host_sincos.argtypes = [C.c_float, fp, fp]
     L.pt_host_sincos.restype = None
     L.pt_ctx_numerics_probe.argtypes = [C.c_void_p, fp, C.c_uint32, fp, fp, fp, fp, u32p]
+    L.pt_ctx_radiance.argtypes = [C.c_void_p, fp, fp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                  fp, C.POINTER(PtStats)]
+    L.pt_ctx_numerics_sweep.argtypes = [C.c_void_p, u64p]
     L.pt_ctx_intersect.argtypes = [C.c_void_p, fp, fp, C.c_uint32, fp, i32p, i32p, fp, fp]
     L.pt_ctx_intersect_bounds.argtypes = [C.c_void_p, C.c_uint32, fp, fp, C.c_uint32, i32p, fp, fp, fp]
     L.pt_ctx_orbit_point.argtypes = [C.c_void_p, fp, fp, C.c_uint32, i32p, fp, i32p, fp]
@@ -392,6 +398,18 @@ def oracle_intersect(scene, o, d):
     L.pto_intersect_batch(C.byref(ps), _np_f(o), _np_f(d), m, _np_f(t), oid.ctypes.data_as(i32p),
                           tid.ctypes.data_as(i32p), _np_f(x), _np_f(nr))
     return t, oid, tid, x, nr
+
+
+def oracle_radiance(scene, o, d, depth, n, seed, pixel):
+    """radiance(&ray, depth, scene) averaged over n samples keyed (seed; pixel, i): (mean rgb, counters)."""
+    L = oracle()
+    o = np.ascontiguousarray(o, dtype=np.float32)
+    d = np.ascontiguousarray(d, dtype=np.float32)
+    out = np.zeros(3, np.float32)
+    cnt = PtoCounters()
+    ps = scene.pto()
+    L.pto_radiance_mean_at(C.byref(ps), _np_f(o), _np_f(d), depth, seed, pixel, n, _np_f(out), C.byref(cnt))
+    return out, cnt
 
 
 def scene_path(sid):

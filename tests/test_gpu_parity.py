@@ -505,6 +505,10 @@ def test_render_multi_and_snapshot(gpu):
     frac, k, img = seen[1]
     ref, _ = gpu_render(gpu, sc, w, h, k, 8)
     assert np.array_equal(img, ref)
+    # ... and, against the oracle: every snapshot is the oracle's frame over that many samples per pixel
+    for _, k2, img2 in (seen[0], seen[1], seen[-1]):
+        want, _, _ = ptlib.oracle_render(sc, w, h, k2, 8)
+        assert np.abs(img2 - want).max() <= TOL, k2
     assert L.pt_device_free(0, d_out) == 0 and L.pt_device_free(0, d_snap) == 0
 
 
@@ -1142,6 +1146,11 @@ def test_cancel_mid_frame_and_progress_cadence(gpu, backend):
     st2 = PtStats()
     assert L.pt_ctx_render(ctx, C.byref(cfg2), d_out, None, None, None, None, C.byref(st2)) == 0, L.pt_last_error()
     assert np.array_equal(part, download()) and st2.ray_bounces == st.ray_bounces
+    # ... and against the oracle: the cancelled frame is the reference's picture over `done` samples per pixel, with
+    # exactly the intersect_scene evaluations of those samples
+    want, cnt, _ = ptlib.oracle_render(sc, w, h, done, 21)
+    assert st.ray_bounces == cnt.ray_bounces
+    assert np.abs(part - want).max() <= TOL
     # default cadence: this frame takes milliseconds, far less than 500 ms -> only the completion is reported
     calls.clear()
     flag[0] = 0
@@ -1210,16 +1219,64 @@ def test_parity_at_baseline_spp(gpu):
         assert err <= TOL, (backend, err)
 
 
-def test_comm_gather_world_1_in_a_clean_process():
-    """pt_comm_* on hardware: RCCL loads (dlopen), a communicator of one rank initialises, and pt_comm_gather_frame
-    (in-place ncclAllGather + the un-permute kernel) returns the rank's own frame, whole and as a band.  Runs in a process
-    of its own (tools/comm_probe.py): this pytest process has imported torch for other tests, and RCCL refuses a process
-    that holds two HIP/HSA runtimes (torch's bundled one and /opt/rocm's).  More ranks need more GPUs than this box has;
-    the partition arithmetic of the un-permute is what test_interleaved_chunks_equal_whole_frame covers."""
+def _comm_gather_world_1(L, ctx):
+    """pt_comm_* at world size 1 on GPU 0: a communicator of one rank, pt_comm_gather_frame (in-place ncclAllGather + the
+    un-permute kernel) must return the rank's own frame, whole and as a band."""
+    sc = ptlib.load_scene_py(ptlib.scene_path("cornell"))
+    assert L.pt_ctx_set_scene(ctx, C.byref(sc.cam), sc.objs, sc.n_objs, sc.tris, sc.n_tris) == 0, L.pt_last_error()
+    w, h, spp = 96, 50, 4
+    npix = w * h
+    ident = C.create_string_buffer(128)
+    assert L.pt_comm_unique_id(ident) == 0, L.pt_last_error()
+    comm = C.c_void_p()
+    assert L.pt_comm_create(0, 0, 1, ident, C.byref(comm)) == 0, L.pt_last_error()
+    d_local, d_frame = C.c_void_p(), C.c_void_p()
+    assert L.pt_device_malloc(0, npix * 12, C.byref(d_local)) == 0 and L.pt_device_malloc(0, npix * 12, C.byref(d_frame)) == 0
+    cfg = PtConfig(w, h, spp, 0, 9, 0, 0, 0, 0)
+    st = PtStats()
+    assert L.pt_ctx_render(ctx, C.byref(cfg), d_local, None, None, None, None, C.byref(st)) == 0, L.pt_last_error()
+    cfg.chunk_pixels = w
+    for _ in range(3):  # the staging buffer is reused across frames
+        assert L.pt_comm_gather_frame(comm, C.byref(cfg), d_local, d_frame, None) == 0, L.pt_last_error()
+    a, b = np.zeros((npix, 3), np.float32), np.zeros((npix, 3), np.float32)
+    assert L.pt_device_download(0, a.ctypes.data_as(C.c_void_p), d_local, npix * 12) == 0
+    assert L.pt_device_download(0, b.ctypes.data_as(C.c_void_p), d_frame, npix * 12) == 0
+    assert a.any() and np.array_equal(a, b), "gathered frame differs from the rank's own"
+    cfg2 = PtConfig(w, h, spp, 0, 9, 7 * w, 31 * w, 0, 0)  # a band: only the band's pixels are gathered
+    assert L.pt_ctx_render(ctx, C.byref(cfg2), d_local, None, None, None, None, C.byref(st)) == 0, L.pt_last_error()
+    cfg2.chunk_pixels = w
+    assert L.pt_comm_gather_frame(comm, C.byref(cfg2), d_local, d_frame, None) == 0, L.pt_last_error()
+    band = np.zeros((24 * w, 3), np.float32)
+    assert L.pt_device_download(0, band.ctypes.data_as(C.c_void_p), d_frame, band.nbytes) == 0
+    assert np.array_equal(band, a[7 * w:31 * w])
+    L.pt_comm_destroy(comm)
+    L.pt_device_free(0, d_local)
+    L.pt_device_free(0, d_frame)
+
+
+def test_comm_gather_world_1_in_this_process_with_torch(gpu):
+    """pt_comm_* on hardware, IN the pytest process and with torch imported into it (round 2 could only run this in a clean
+    subprocess: `ncclCommInitRank: unhandled cuda error`).  This process loaded libptrace_hip.so - and with it /opt/rocm's
+    HIP runtime - before torch brings its bundled libamdhip64 / librccl (same sonames): pt_comm must pick the RCCL that
+    sits next to the HIP runtime this library is bound to, not whichever copy answers to the soname (csrc/pt_comm.hip).
+    No PT_RCCL_LIB.  More ranks need more GPUs than this box has; the partition arithmetic of the un-permute is what
+    test_interleaved_chunks_equal_whole_frame covers."""
+    assert "PT_RCCL_LIB" not in os.environ
+    import torch  # noqa: F401  (maps torch/lib/libamdhip64.so, libhsa-runtime64.so, librccl.so into this process)
+    assert torch.cuda.device_count() >= 1
+    L, ctx = gpu
+    _comm_gather_world_1(L, ctx)
+
+
+@pytest.mark.parametrize("order", ["none", "first", "after"])
+def test_comm_gather_world_1_load_orders(order):
+    """The same in processes of their own, with torch imported before the library (bench.py's order: the library then binds
+    to torch's HIP runtime and must use torch's RCCL), after it, or not at all (tools/comm_probe.py)."""
     import subprocess
     import sys
-    r = subprocess.run([sys.executable, os.path.join(ptlib.ROOT, "tools", "comm_probe.py")], capture_output=True, text=True,
-                       timeout=300)
+    env = {k: v for k, v in os.environ.items() if k != "PT_RCCL_LIB"}
+    r = subprocess.run([sys.executable, os.path.join(ptlib.ROOT, "tools", "comm_probe.py"), order], capture_output=True,
+                       text=True, timeout=600, env=env)
     assert r.returncode == 0 and "gather ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
@@ -1284,3 +1341,202 @@ def test_large_call_in_parts_cancel_and_snapshot(gpu):
     if n_snap == done2:
         assert np.array_equal(snap[part:2 * part], got[part:2 * part])
     assert L.pt_device_free(0, d_out) == 0 and L.pt_device_free(0, d_snap) == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 3: pt_ctx_radiance (radiance(&ray, depth, scene) of one ray on the device), the hand-derived shading KATs through
+# it, the exhaustive sqrt / reciprocal sweep, memory-aware pass sizing
+import kats_shading
+
+FLAG_SEPARATE_KERNELS = 2
+# every device path: (backend, flags, the kernel it must report for scenes without BVH meshes)
+DEVICE_PATHS = [(0, 0, b"k_pass_cand"), (0, ptlib.FLAG_NO_BVH, b"k_pass"), (0, FLAG_SEPARATE_KERNELS, b"k_intersect"),
+                (1, 0, None)]
+
+
+def gpu_radiance(gpu, o, d, depth, n, seed, pixel, backend=0, flags=0):
+    L, ctx = gpu
+    o = np.ascontiguousarray(o, dtype=np.float32)
+    d = np.ascontiguousarray(d, dtype=np.float32)
+    out = np.zeros(3, np.float32)
+    st = PtStats()
+    rc = L.pt_ctx_radiance(ctx, _np_f(o), _np_f(d), depth, n, seed, pixel, backend, flags, _np_f(out), C.byref(st))
+    assert rc == 0, L.pt_last_error()
+    return out, st
+
+
+def test_exhaustive_sqrt_and_reciprocal_sweep(gpu):
+    """The device's short f_sqrt / f_rcp sequences (csrc/pt_math.h) against the compiler's IEEE expansions: f_sqrt on
+    all 2^32 binary32 bit patterns, f_rcp on every normal divisor with 2^-126 <= |d| <= 2^126.  No input may differ."""
+    L, ctx = gpu
+    out = (C.c_uint64 * 4)()
+    assert L.pt_ctx_numerics_sweep(ctx, out) == 0, L.pt_last_error()
+    assert out[2] == 1 << 32 and out[3] == 2 * (252 * (1 << 23) + 1), list(out)
+    assert out[0] == 0 and out[1] == 0, "f_sqrt mismatches %d, f_rcp mismatches %d" % (out[0], out[1])
+
+
+@pytest.mark.parametrize("name,build,o,d,depth,want", kats_shading.CASES, ids=[c[0] for c in kats_shading.CASES])
+def test_hand_derived_shading_kats_through_the_c_abi(gpu, name, build, o, d, depth, want):
+    """tests/kats_shading.py (specular / refract / Fresnel / roulette / MAX_DEPTH worked out by hand from mod.rs:661-792)
+    through pt_ctx_radiance on every device path: against the hand value and against the oracle's radiance() on the same
+    RNG streams, with equal intersect_scene counts."""
+    L, ctx = gpu
+    sc = build()
+    set_scene(gpu, sc)
+    for backend, flags, kernel in DEVICE_PATHS:
+        if kernel is not None:
+            assert L.pt_ctx_pass_kernel(ctx, flags) == kernel
+        tag = (name, backend, flags)
+        if want[0] == "exact":
+            for n, pixel in ((1, 0), (1, 7), (257, 3)):
+                got, st = gpu_radiance(gpu, o, d, depth, n, 11, pixel, backend, flags)
+                ref, cnt = ptlib.oracle_radiance(sc, o, d, depth, n, 11, pixel)
+                assert st.ray_bounces == cnt.ray_bounces, tag
+                assert np.allclose(got, want[1], rtol=2e-6, atol=0), (tag, got, want[1])
+                # (the oracle sums its n samples one after the other in f32 as the reference's test does: 257 equal values
+                # drift by a few 1e-7 each; the device's fixed-point sum does not)
+                assert np.allclose(got, ref, rtol=2e-6 if n == 1 else 2e-5, atol=0), (tag, got, ref)
+            continue
+        _, a, b, p_a = want
+        seen_a = seen_b = 0
+        for pixel in range(24):  # one sample each: the oracle says which of the two outcomes
+            got, st = gpu_radiance(gpu, o, d, depth, 1, 11, pixel, backend, flags)
+            ref, cnt = ptlib.oracle_radiance(sc, o, d, depth, 1, 11, pixel)
+            assert st.ray_bounces == cnt.ray_bounces, tag
+            is_a = np.array_equal(ref, a)
+            assert is_a or np.array_equal(ref, b), tag
+            assert np.allclose(got, ref, rtol=2e-6, atol=0), (tag, pixel, got, ref)
+            seen_a += is_a
+            seen_b += not is_a
+        assert seen_a > 0 and seen_b > 0, tag
+        n = 20000
+        got, st = gpu_radiance(gpu, o, d, depth, n, 11, 5, backend, flags)
+        ref, cnt = ptlib.oracle_radiance(sc, o, d, depth, n, 11, 5)
+        assert st.ray_bounces == cnt.ray_bounces, tag
+        # (20 000 values summed one after the other in f32 by the oracle, as the reference's test does: 1e-5 of drift; the
+        # bar is the north star's 1e-4)
+        assert np.allclose(got, ref, rtol=1e-4, atol=1e-7), (tag, got, ref)
+        mean = p_a * a.astype(np.float64) + (1.0 - p_a) * b.astype(np.float64)
+        sd = np.abs(a.astype(np.float64) - b.astype(np.float64)) * np.sqrt(p_a * (1.0 - p_a) / n)
+        assert np.all(np.abs(got - mean) <= 5.0 * sd + 1e-6), (tag, got, mean)
+
+
+def test_reference_radiance_test_run_literally(gpu):
+    """src/render/test.rs:146-183 (`test_radiance`) as the reference runs it: radiance(&ray, 0, &scene) of the ray
+    (0,0,0) -> (0,0,-1), 10 000 times, the sum divided by their number; it asserts .x > 0.3 (analytic 50/144).  Through
+    pt_ctx_radiance on every device path, and against the oracle's loop over the same RNG streams."""
+    cam = ptlib.make_camera((0, 0, 0.035), (0, 0, -1))
+    sc = ptlib.Scene("t", cam, [ptlib.make_sphere((0, 0, -3), 1.0, (1, 0, 0), (0, 0, 0), "Diffuse"),
+                                ptlib.make_sphere((0, 0, 10), 1.0, (0, 0, 0), (50, 50, 50), "Diffuse")], [])
+    set_scene(gpu, sc)
+    o, d = (0, 0, 0), (0, 0, -1)
+    ref, cnt = ptlib.oracle_radiance(sc, o, d, 0, 10000, 1, 0)
+    assert ref[0] > 0.3
+    for backend, flags, _ in DEVICE_PATHS:
+        got, st = gpu_radiance(gpu, o, d, 0, 10000, 1, 0, backend, flags)
+        assert got[0] > 0.3 and abs(got[0] - 50.0 / 144.0) < 0.03, got
+        assert got[1] == 0.0 and got[2] == 0.0
+        assert st.ray_bounces == cnt.ray_bounces
+        assert abs(got[0] - ref[0]) <= 1e-4, (got, ref)
+
+
+def test_radiance_probe_on_the_shipped_scenes(gpu):
+    """pt_ctx_radiance against the oracle on cornell.json and mesh.json (diffuse sampling, glass, BVH walks): camera rays
+    of a few pixels, 2 000 samples each, both backends."""
+    for sid in ("cornell", "mesh"):
+        sc = ptlib.load_scene_py(ptlib.scene_path(sid))
+        set_scene(gpu, sc)
+        O = ptlib.oracle()
+        for pixel in (100 * 64 + 17, 300 * 64 + 40):
+            ro, rd = np.zeros(3, np.float32), np.zeros(3, np.float32)
+            O.pto_primary_ray(C.byref(sc.cam), 64, 48, pixel % (64 * 48), 0, 5, _np_f(ro), _np_f(rd))
+            ref, cnt = ptlib.oracle_radiance(sc, ro, rd, 0, 2000, 9, pixel)
+            for backend in (0, 1):
+                got, st = gpu_radiance(gpu, ro, rd, 0, 2000, 9, pixel, backend, 0)
+                assert st.ray_bounces == cnt.ray_bounces, (sid, pixel, backend)
+                assert np.allclose(got, ref, rtol=2e-5, atol=1e-6), (sid, pixel, backend, got, ref)
+
+
+def _render_dev(L, ctx, sc, w, h, spp, seed, flags=0, rays_per_pass=0):
+    nbytes = w * h * 12
+    d_out = C.c_void_p()
+    assert L.pt_device_malloc(0, nbytes, C.byref(d_out)) == 0, L.pt_last_error()
+    cfg = PtConfig(w, h, spp, 0, seed, 0, 0, rays_per_pass, flags)
+    st = PtStats()
+    rc = L.pt_ctx_render(ctx, C.byref(cfg), d_out, None, None, None, None, C.byref(st))
+    assert rc == 0, L.pt_last_error()
+    host = np.zeros((w * h, 3), dtype=np.float32)
+    assert L.pt_device_download(0, host.ctypes.data_as(C.c_void_p), d_out, nbytes) == 0
+    assert L.pt_device_free(0, d_out) == 0
+    return host, st
+
+
+def test_memory_budget_changes_the_passes_not_the_image(gpu):
+    """pt_ctx_set_memory_budget: 8 MiB of ray queues hold 23 831 primary rays (352 B each) - one sample per pixel and pass
+    on a 128x96 frame instead of all 64 in one pass.  Same bits, same bounce count."""
+    L, ctx = gpu
+    sc = ptlib.load_scene_py(ptlib.scene_path("cornell"))
+    set_scene(gpu, sc)
+    w, h, spp = 128, 96, 64
+    whole, st0 = _render_dev(L, ctx, sc, w, h, spp, 4)
+    assert st0.passes == 1
+    assert L.pt_ctx_set_memory_budget(ctx, 8 << 20) == 0
+    try:
+        small, st1 = _render_dev(L, ctx, sc, w, h, spp, 4)
+    finally:
+        assert L.pt_ctx_set_memory_budget(ctx, 0) == 0
+    assert st1.passes == spp and st1.ray_bounces == st0.ray_bounces
+    assert np.array_equal(small, whole)
+
+
+def test_default_pass_size_is_shared_by_pipelines_and_ranks(gpu):
+    """Eight pipelines (PT_FLAG_PIPELINES) and eight ranks of pt_render_multi on this box's ONE GPU with the default
+    rays_per_pass on the baseline frame size: each context sizes its ray queues to an eighth of the default (round 2: 8 x 36 GB
+    of queues, PT_ERR_HIP on a 288 GB device).  Same bits as the single pipeline."""
+    L, ctx = gpu
+    sc = ptlib.load_scene_py(ptlib.scene_path("cornell"))
+    set_scene(gpu, sc)
+    w, h, spp = 1024, 768, 256
+    one, st = _render_dev(L, ctx, sc, w, h, spp, 2)
+    eight, st8 = _render_dev(L, ctx, sc, w, h, spp, 2, flags=8 << 8)
+    assert st8.ray_bounces == st.ray_bounces and np.array_equal(eight, one)
+    cfg = PtConfig(w, h, spp, 0, 2, 0, 0, 0, 0)
+    out = np.zeros((w * h, 3), dtype=np.float32)
+    s2 = PtStats()
+    seen = []
+    cb = ptlib.PROGRESS_FN(lambda user, frac: seen.append(frac))
+    rc = L.pt_render_multi(C.byref(cfg), 8, C.byref(sc.cam), sc.objs, sc.n_objs, sc.tris, sc.n_tris, _np_f(out), None,
+                           C.cast(cb, C.c_void_p), None, C.byref(s2))
+    assert rc == 0, L.pt_last_error()
+    assert s2.ray_bounces == st.ray_bounces and np.array_equal(out, one)
+    assert seen and seen[-1] == 1.0 and seen.count(1.0) == 1  # the completion is reported once, by the caller's thread, at the end
+
+
+def test_out_of_device_memory_halves_the_pass(gpu):
+    """A pass whose ray queues do not fit what is left of the device is halved until it does (DevBuf::ensure reports the
+    failed allocation, render_wavefront retries): most of the HBM is taken by other allocations first, then a frame is asked
+    for with 256 Mi primary rays per pass (90 GB of queues).  Same bits as the frame rendered at leisure."""
+    L, _ = gpu
+    sc = ptlib.load_scene_py(ptlib.scene_path("cornell"))
+    ctx = C.c_void_p()
+    assert L.pt_ctx_create(0, C.byref(ctx)) == 0, L.pt_last_error()
+    assert L.pt_ctx_set_scene(ctx, C.byref(sc.cam), sc.objs, sc.n_objs, sc.tris, sc.n_tris) == 0
+    w, h, spp = 1024, 768, 512
+    want, st0 = _render_dev(L, ctx, sc, w, h, spp, 6, rays_per_pass=8 << 20)
+    hogs = []
+    try:
+        while len(hogs) < 40:  # 8 GiB at a time until the device refuses
+            p = C.c_void_p()
+            if L.pt_device_malloc(0, 8 << 30, C.byref(p)) != 0:
+                break
+            hogs.append(p)
+        assert len(hogs) >= 8, "could not even take 64 GiB"
+        for _ in range(3):  # leave 24 GiB (+ the remainder) free
+            L.pt_device_free(0, hogs.pop())
+        got, st1 = _render_dev(L, ctx, sc, w, h, spp, 6, rays_per_pass=256 << 20)
+    finally:
+        for p in hogs:
+            L.pt_device_free(0, p)
+        L.pt_ctx_destroy(ctx)
+    assert st1.passes > 2, st1.passes  # 256 Mi rays would have been two passes
+    assert st1.ray_bounces == st0.ray_bounces and np.array_equal(got, want)

@@ -1,5 +1,6 @@
 """Host-side pieces of the device layout that can be checked without a GPU: the round-robin deal of pixels to ray
 streams (pt_device.h: stream_pixel / stream_pixel_count / global_pixel) and the bookkeeping word."""
+import ctypes as C
 import os
 import subprocess
 import textwrap
@@ -168,3 +169,22 @@ def test_flatten_tables_of_the_walk_queue(tmp_path):
     assert out[0] == "OK" and out[1] == "1" and int(out[2]) > int(out[3]) >= 5  # one BVH mesh; stack deeper than the tree
     out = subprocess.check_output([exe, ptlib.scene_path("cornell"), ptlib.ROOT]).decode().split()
     assert out[:2] == ["OK", "0"]
+
+
+def test_bvh_reference_limit():
+    """The BVH walkers pack a node index or a leaf code (first pair record << 2 | records - 1) into 26 bits of a queue entry
+    (csrc/pt_device.h: WalkQueue, LeafLds); flatten_scene refuses a scene beyond that instead of letting references wrap."""
+    L = ptlib.product()
+    L.pt_bvh_refs_fit.argtypes = [C.c_uint64, C.c_uint64]
+    assert L.pt_bvh_refs_fit(141, 300) == 1                      # mesh.json
+    assert L.pt_bvh_refs_fit((1 << 26) - 1, 1000) == 1
+    assert L.pt_bvh_refs_fit(1 << 26, 1000) == 0                 # node indices need 27 bits
+    assert L.pt_bvh_refs_fit(1000, (1 << 24) - 1) == 1
+    assert L.pt_bvh_refs_fit(1000, 1 << 24) == 0                 # leaf codes need 27 bits
+
+
+def test_build_flags_are_reported():
+    L = ptlib.product()
+    L.pt_build_flags.restype = C.c_char_p
+    flags = L.pt_build_flags().decode()
+    assert all(tok.startswith("-") or tok == "" for tok in flags.split(" ")), flags

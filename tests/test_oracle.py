@@ -377,3 +377,35 @@ def test_oracle_reproduces_golden_numerics():
         assert np.array_equal(out, want)
     gi = np.array([O.pto_to_int_with_gamma_correction(float(v)) for v in g["gamma_x"]], np.uint32)
     assert np.array_equal(gi, g["gamma_int"])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 3: hand-derived KATs for the shading half of radiance() (tests/kats_shading.py), on the oracle
+import kats_shading
+
+
+@pytest.mark.parametrize("name,build,o,d,depth,want", kats_shading.CASES, ids=[c[0] for c in kats_shading.CASES])
+def test_hand_derived_shading_kats(name, build, o, d, depth, want):
+    """mod.rs:661-792 worked out by hand on exact geometry: the oracle's radiance() must return the closed expression."""
+    sc = build()
+    if want[0] == "exact":
+        for pixel in range(16):
+            got, cnt = ptlib.oracle_radiance(sc, o, d, depth, 1, 11, pixel)
+            assert np.array_equal(got, want[1]), (name, pixel, got, want[1])
+        got, _ = ptlib.oracle_radiance(sc, o, d, depth, 64, 11, 3)
+        assert np.allclose(got, want[1], rtol=1e-6, atol=0), (name, got)
+        return
+    _, a, b, p_a = want
+    seen_a = seen_b = 0
+    for pixel in range(64):  # one sample each: one of the two outcomes, exactly
+        got, _ = ptlib.oracle_radiance(sc, o, d, depth, 1, 11, pixel)
+        is_a, is_b = np.array_equal(got, a), np.array_equal(got, b)
+        assert is_a or is_b, (name, pixel, got, a, b)
+        seen_a += is_a
+        seen_b += is_b
+    assert seen_a > 0 and seen_b > 0, (name, seen_a, seen_b)
+    n = 20000
+    got, _ = ptlib.oracle_radiance(sc, o, d, depth, n, 11, 5)
+    mean = p_a * a.astype(np.float64) + (1.0 - p_a) * b.astype(np.float64)
+    sd = np.abs(a.astype(np.float64) - b.astype(np.float64)) * np.sqrt(p_a * (1.0 - p_a) / n)
+    assert np.all(np.abs(got - mean) <= 5.0 * sd + 1e-6), (name, got, mean, sd)
