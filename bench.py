@@ -352,7 +352,8 @@ def main():
                     "value": vs["bounces"] / vs["dt"], "unit": "ray-bounces/s",
                     "ms_per_step": 1e3 * vs["dt"] / max(1, min(args.steps, 2)),
                     "image_identical_to_main_backend": bool(torch.equal(vs["image"], main_run["image"])),
-                    "roofline_k_intersect": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "roofline_k_intersect": {"kernel": ctx.pass_kernel(separate_kernels=True), "bound": "hbm", "achieved": ach,
+                                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                              "frac": ach / HBM_PEAK_GBS, "bytes_per_ray": INTERSECT_BYTES_PER_RAY,
                                              "avg_launch_ms": vs["isect_ms"] / max(1, vs["launches"]),
                                              "rays_per_s": vs["isect_rays"] / (vs["isect_ms"] * 1e-3)}}

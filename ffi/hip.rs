@@ -1,4 +1,4 @@
-//! src/render/hip.rs — binding of libptrace_hip.so (include/ptrace.h, ABI 3) for filippo-orru/path-tracer-rust.
+//! src/render/hip.rs — binding of libptrace_hip.so (include/ptrace.h, ABI 4) for filippo-orru/path-tracer-rust.
 //!
 //! NOT COMPILED HERE: the build image has no Rust toolchain.  This is the file a maintainer adds as `mod hip;` in
 //! `src/render/mod.rs` (a child module of `render`, so it may read the private fields of `Mesh` and
@@ -11,6 +11,7 @@ use glam::Vec3;
 use std::ffi::{c_void, CStr};
 use std::os::raw::c_char;
 use std::sync::atomic::{AtomicBool, AtomicUsize, Ordering};
+use std::sync::Mutex;
 
 #[repr(C)]
 #[derive(Clone, Copy, Default)]
@@ -81,6 +82,12 @@ pub const PT_CANCELLED: i32 = -4;
 
 pub type PtProgressFn = extern "C" fn(user: *mut c_void, fraction: f32);
 
+/// opaque `pt_ctx` of include/ptrace.h: one GPU, one stream, the device copies of one scene and the ray queues
+#[repr(C)]
+pub struct PtCtx {
+    _private: [u8; 0],
+}
+
 #[link(name = "ptrace_hip")]
 extern "C" {
     pub fn pt_render(
@@ -96,6 +103,32 @@ extern "C" {
         user: *mut c_void,
         stats: *mut PtStats,
     ) -> i32;
+    // the resident form: scene tables and ray queues stay in HBM across frames, the frame is written to device memory,
+    // and the progress callback may pull what has been accumulated so far (pt_ctx_snapshot)
+    pub fn pt_ctx_create(device: i32, out: *mut *mut PtCtx) -> i32;
+    pub fn pt_ctx_destroy(ctx: *mut PtCtx);
+    pub fn pt_ctx_set_scene(
+        ctx: *mut PtCtx,
+        cam: *const PtCamera,
+        objs: *const PtObject,
+        n_objs: u32,
+        tris: *const PtTriangle,
+        n_tris: u32,
+    ) -> i32;
+    pub fn pt_ctx_render(
+        ctx: *mut PtCtx,
+        cfg: *const PtConfig,
+        d_out_rgb: *mut c_void,
+        hip_stream: *mut c_void,
+        cancel: *const u8,
+        cb: Option<PtProgressFn>,
+        user: *mut c_void,
+        stats: *mut PtStats,
+    ) -> i32;
+    pub fn pt_ctx_snapshot(ctx: *mut PtCtx, d_out_rgb: *mut c_void, spp_done: *mut u32) -> i32;
+    pub fn pt_device_malloc(device: i32, bytes: usize, out: *mut *mut c_void) -> i32;
+    pub fn pt_device_free(device: i32, p: *mut c_void) -> i32;
+    pub fn pt_device_download(device: i32, dst_host: *mut c_void, src_device: *const c_void, bytes: usize) -> i32;
     pub fn pt_last_error() -> *const c_char;
     pub fn pt_device_count() -> i32;
     pub fn pt_image_hash(rgb: *const f32, n_floats: usize) -> u64;
@@ -155,81 +188,136 @@ pub fn flatten(scene: &SceneData) -> (PtCamera, Vec<PtObject>, Vec<PtTriangle>) 
     (cam, objs, tris)
 }
 
-struct Progress<'a> {
+fn last_error() -> String {
+    unsafe { CStr::from_ptr(pt_last_error()) }.to_string_lossy().into_owned()
+}
+
+/// what the progress callback needs: the counter and the pixel buffer the reference's 500 ms thread reads (:960-976)
+struct Preview<'a> {
+    ctx: *mut PtCtx,
+    d_snap: *mut c_void,
+    pixels: &'a Mutex<Vec<Vec3>>,
     processed_pixel_count: &'a AtomicUsize,
     grid_size: usize,
 }
 
+/// Called by the library between passes, at most every 500 ms (pt_config.progress_ms = 0: the reference's RenderUpdate
+/// cadence, :965-982), on the thread that called pt_ctx_render.  Drives the counter the progress thread reads (:966-968) and
+/// puts the picture accumulated so far into `pixels`, so that the RenderUpdate that thread sends next (:969-972) carries a
+/// partial image: pt_ctx_snapshot resolves the accumulators into device memory (every pixel over the samples it has so far
+/// - the reference's partial image is a random subset of finished pixels, this one is the whole frame at partial spp),
+/// one download, one copy under the mutex (held for a memcpy, as render_pixel_to_vec holds it for one store, :1013-1014).
 extern "C" fn on_progress(user: *mut c_void, fraction: f32) {
-    // drives the counter the 500 ms thread reads (:960-975); no image copy here - see the note at the bottom
-    let p = unsafe { &*(user as *const Progress) };
+    let p = unsafe { &*(user as *const Preview) };
     p.processed_pixel_count
         .store((fraction * p.grid_size as f32) as usize, Ordering::Relaxed);
+    if fraction >= 1.0 {
+        return; // the finished frame is copied by render_pixels_hip itself
+    }
+    let mut spp_done: u32 = 0;
+    if unsafe { pt_ctx_snapshot(p.ctx, p.d_snap, &mut spp_done) } != PT_OK {
+        return; // nothing accumulated yet
+    }
+    let mut local = vec![Vec3::default(); p.grid_size];
+    let bytes = p.grid_size * 3 * std::mem::size_of::<f32>();
+    if unsafe { pt_device_download(0, local.as_mut_ptr() as *mut c_void, p.d_snap, bytes) } == PT_OK {
+        p.pixels.lock().unwrap().copy_from_slice(&local);
+    }
 }
 
 /// Replaces the parallel section :1017-1024: fills `pixels` (index (H-1-y)*W+x, :805-806; glam::Vec3 is
-/// #[repr(C)] 3 x f32, so the Vec's memory IS the out_rgb layout).  `cancel` is the flag render() already owns
-/// (`stop_render`, :943): one byte, read by the library between passes.
+/// #[repr(C)] 3 x f32, so the Vec's memory IS the out_rgb layout) and keeps it filled with the partial picture while the
+/// frame renders.  `cancel` is the flag render() already owns (`stop_render`, :943): one byte, read by the library between
+/// passes (a few milliseconds apart; the reference polls it every 100 ms, :947-958).
 pub fn render_pixels_hip(
     cfg: &RenderConfig,
-    pixels: &mut [Vec3],
+    pixels: &Mutex<Vec<Vec3>>,
     cancel: &AtomicBool,
     processed_pixel_count: &AtomicUsize,
     seed: u64,
 ) -> Result<PtStats, String> {
     let (cam, objs, tris) = flatten(&cfg.scene);
     let grid_size = cfg.resolution.width * cfg.resolution.height;
-    assert_eq!(pixels.len(), grid_size);
+    let bytes = grid_size * 3 * std::mem::size_of::<f32>();
     let c = PtConfig {
         width: cfg.resolution.width as u32,
         height: cfg.resolution.height as u32,
         spp: cfg.samples_per_pixel as u32,
         seed,
-        ..Default::default()
+        ..Default::default() // progress_ms = 0: a callback at most every 500 ms
     };
-    let progress = Progress {
-        processed_pixel_count,
-        grid_size,
-    };
+    let mut ctx: *mut PtCtx = std::ptr::null_mut();
+    let (mut d_out, mut d_snap): (*mut c_void, *mut c_void) = (std::ptr::null_mut(), std::ptr::null_mut());
     let mut st = PtStats::default();
     let rc = unsafe {
-        pt_render(
-            &c,
-            &cam,
-            objs.as_ptr(),
-            objs.len() as u32,
-            tris.as_ptr(),
-            tris.len() as u32,
-            pixels.as_mut_ptr() as *mut f32,
-            cancel.as_ptr() as *const u8,
-            Some(on_progress),
-            &progress as *const Progress as *mut c_void,
-            &mut st,
-        )
+        let mut rc = pt_ctx_create(0, &mut ctx);
+        if rc == PT_OK {
+            rc = pt_ctx_set_scene(ctx, &cam, objs.as_ptr(), objs.len() as u32, tris.as_ptr(), tris.len() as u32);
+        }
+        if rc == PT_OK {
+            rc = pt_device_malloc(0, bytes, &mut d_out);
+        }
+        if rc == PT_OK {
+            rc = pt_device_malloc(0, bytes, &mut d_snap);
+        }
+        if rc == PT_OK {
+            let preview = Preview {
+                ctx,
+                d_snap,
+                pixels,
+                processed_pixel_count,
+                grid_size,
+            };
+            rc = pt_ctx_render(
+                ctx,
+                &c,
+                d_out,
+                std::ptr::null_mut(),
+                cancel.as_ptr() as *const u8,
+                Some(on_progress),
+                &preview as *const Preview as *mut c_void,
+                &mut st,
+            );
+        }
+        if rc == PT_OK || rc == PT_CANCELLED {
+            // the finished frame - or, cancelled, every pixel over the samples that were accumulated (the reference's
+            // cancelled image holds its finished pixels and black elsewhere, :1003-1016)
+            let mut local = vec![Vec3::default(); grid_size];
+            let rc2 = pt_device_download(0, local.as_mut_ptr() as *mut c_void, d_out, bytes);
+            if rc2 == PT_OK {
+                pixels.lock().unwrap().copy_from_slice(&local);
+            } else {
+                rc = rc2;
+            }
+        }
+        rc
     };
+    let msg = if rc == PT_OK || rc == PT_CANCELLED { String::new() } else { last_error() };
+    unsafe {
+        pt_device_free(0, d_snap);
+        pt_device_free(0, d_out);
+        pt_ctx_destroy(ctx);
+    }
     match rc {
-        PT_OK | PT_CANCELLED => Ok(st), // cancelled: the partial image is in `pixels`, as with the reference (:1003-1016)
-        _ => Err(unsafe { CStr::from_ptr(pt_last_error()) }
-            .to_string_lossy()
-            .into_owned()),
+        PT_OK | PT_CANCELLED => Ok(st),
+        _ => Err(msg),
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The edit in render() (:1001-1024).  The mutex around `pixels` is held by the 500 ms thread while it clones the
-// buffer (:972-976), so the GPU call must not hold it for the whole frame: render into a local buffer and copy.
+// The edit in render() (:1001-1024).  `pixels` is the Arc<Mutex<Vec<Vec3>>> render() already owns (:938) and the 500 ms
+// thread clones under its lock (:969-972); render_pixels_hip only takes the lock for a memcpy.
 //
 //     let render_pixel_to_vec = ...;                       // unchanged (CPU path)
 //     if hip::pt_device_count() > 0 && !MOCK_RANDOM {
-//         let mut local = vec![Vec3::default(); grid_size];
 //         let seed = rand::random::<u64>();                // the reference is OS-seeded too (:53)
-//         match hip::render_pixels_hip(&render_config, &mut local, &stop_render, &processed_pixel_count, seed) {
+//         match hip::render_pixels_hip(&render_config, &pixels, &stop_render, &processed_pixel_count, seed) {
 //             Ok(stats) => println!("GPU: {} ray bounces in {:.1} ms", stats.ray_bounces, stats.ms_total),
 //             Err(msg) => panic!("libptrace_hip: {msg}"),  // the reference unwraps its own errors (:1032,1042)
 //         }
-//         pixels.lock().unwrap().copy_from_slice(&local);
 //     } else if MOCK_RANDOM { ... } else { ... rayon ... } // unchanged
 //
-// Progressive images in RenderUpdate (:972-976) stay black until the copy above; a host that wants the partial frame
-// every 500 ms uses the resident form instead (pt_ctx_create / pt_ctx_set_scene / pt_ctx_render with a callback that
-// calls pt_ctx_snapshot and copies the snapshot into `pixels`): include/ptrace.h, "Progressive preview".
+// RenderUpdate { progress, image } (:969-972) then carries the growing picture every 500 ms exactly as with the CPU path:
+// the progress thread is untouched, it finds `pixels` refreshed by on_progress.  A host that renders many frames of one
+// scene (the GUI re-renders on every camera move) keeps the PtCtx and the two device buffers instead of creating them per
+// frame: pt_ctx_set_scene only when the scene changed.

@@ -199,7 +199,9 @@ int pt_ctx_set_profiling(pt_ctx *ctx, int enabled);
  * pt_stats.intersect_launches / ms_intersect describe: "k_pass_cand" (one launch per pass, candidate scan: scenes
  * without BVH meshes), "k_pass_cand_bvh" (the same kernel's form for scenes with BVH meshes: candidate scan + parked
  * walks), "k_pass" (every triangle tested per ray), "k_pass_bvh" (scan + depth-first parked walks: PT_CAND_BVH=0),
- * or "k_intersect" (separate kernels).  For profilers and bench.py; NULL without a scene. */
+ * or, with separate kernels, "k_intersect_cand" (the stand-alone intersect step with the candidate scan: scenes without BVH
+ * meshes) / "k_intersect" (every triangle per ray, or scan + walks for BVH scenes).  For profilers and bench.py; NULL without
+ * a scene. */
 const char *pt_ctx_pass_kernel(const pt_ctx *ctx, uint32_t flags);
 
 /* radiance(&ray, depth, &scene) (mod.rs:661-792) for ONE given ray, averaged over n_samples independent evaluations:

@@ -38,7 +38,8 @@
  * lines ("parity unpinned" by the reference's own tests).
  *
  * RNG contract (shared with the HIP path, which must draw bit-identical numbers):
- *   Philox4x32-10, key = (seed_lo, seed_hi), counter = (pixel_idx, sample_idx, tag, 0),
+ *   Philox4x32-7 (Random123's philox4x32_R(7, ..): the fewest rounds its authors report as Crush-resistant; rounds 1-2 of
+ *   this build drew with ten), key = (seed_lo, seed_hi), counter = (pixel_idx, sample_idx, tag, 0),
  *   tag = 0 for the two camera draws of a sample (word0 -> r1/x, word1 -> r2/y, mod.rs:818-819),
  *   tag = (branch << 8) | new_depth for one radiance() invocation:
  *         word0 -> Russian roulette (mod.rs:678), word1 -> diffuse r1 (mod.rs:691) or the
@@ -180,7 +181,7 @@ void pto_sincos_vs_libm(uint32_t k_begin, uint32_t k_end, uint64_t *sin_mismatch
     *cos_mismatch = mc;
 }
 
-/* ------------------------------------------------------------------ Philox4x32-10 */
+/* ------------------------------------------------------------------ Philox4x32-R (Random123) */
 static inline void philox_round(uint32_t c[4], uint32_t k0, uint32_t k1) {
     uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
     uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
@@ -194,16 +195,20 @@ static inline void philox_round(uint32_t c[4], uint32_t k0, uint32_t k1) {
     c[3] = n3;
 }
 
-void pto_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+void pto_philox4x32(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4]) {
     uint32_t c[4] = {ctr[0], ctr[1], ctr[2], ctr[3]};
     uint32_t k0 = key[0], k1 = key[1];
-    for (int r = 0; r < 10; r++) {
+    for (int r = 0; r < rounds; r++) {
         philox_round(c, k0, k1);
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }
     memcpy(out, c, 16);
 }
+void pto_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { pto_philox4x32(ctr, key, 10, out); }
+/* the rounds the RNG contract draws with: Random123's philox4x32_R(7, ..) */
+#define PTO_PHILOX_ROUNDS 7
+void pto_philox4x32_7(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { pto_philox4x32(ctr, key, PTO_PHILOX_ROUNDS, out); }
 
 /* rand 0.8.5 Standard<f32>: 24 high bits -> [0,1) */
 float pto_u32_to_unit(uint32_t u) { return (float)(u >> 8) * (1.0f / 16777216.0f); }
@@ -212,7 +217,7 @@ static inline void draw4(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_
     uint32_t ctr[4] = {pixel, sample, tag, 0u};
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
     uint32_t o[4];
-    pto_philox4x32_10(ctr, key, o);
+    pto_philox4x32_7(ctr, key, o);
     for (int i = 0; i < 4; i++) u[i] = pto_u32_to_unit(o[i]);
 }
 

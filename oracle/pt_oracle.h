@@ -41,7 +41,9 @@ void pto_vec_ops(const float *a, const float *b, float s, float *out23);
 float pto_sinf(float y);
 float pto_cosf(float y);
 void pto_sincos_vs_libm(uint32_t k_begin, uint32_t k_end, uint64_t *sin_mismatch, uint64_t *cos_mismatch);
+void pto_philox4x32(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4]);
 void pto_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void pto_philox4x32_7(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]); /* the contract's generator */
 float pto_u32_to_unit(uint32_t u);
 void pto_draw4(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t tag, float u[4]);
 float pto_gamma_correction(float x);

@@ -881,7 +881,7 @@ const char *pt_ctx_pass_kernel(const pt_ctx *c, uint32_t flags) {
     const uint32_t n_nodes = no_bvh ? 0u : c->n_bvh_nodes;
     const bool bvh_ok = n_nodes == 0u || (!(c->scene.bvh_in_lds & 1u) && c->tune.pass_bvh);
     const bool one_kernel = bvh_ok && c->tune.pass_kernel && !(flags & PT_FLAG_SEPARATE_KERNELS);
-    if (!one_kernel) return "k_intersect";
+    if (!one_kernel) return (n_nodes == 0u && cand_scan_for(c, flags)) ? "k_intersect_cand" : "k_intersect";
     if (cand_scan_for(c, flags)) return n_nodes != 0u ? "k_pass_cand_bvh" : "k_pass_cand";  // (k_pass_cand<.., BVH = true>)
     return n_nodes != 0u ? "k_pass_bvh" : "k_pass";
 }

@@ -125,7 +125,10 @@ struct alignas(16) FlatPairRec {
     uint32_t pad0;
 };
 constexpr uint32_t kNoPair = 0xffffffffu;
-constexpr float kGrazing = 1.0f / 64.0f;  // |d_a| below this: the filter does not judge, the exact test does
+#ifndef PT_GRAZING_INV
+#define PT_GRAZING_INV 64.0f
+#endif
+constexpr float kGrazing = 1.0f / PT_GRAZING_INV;  // |d_a| below this: the filter does not judge, the exact test does
 constexpr uint32_t kCandQueueCap = 256;   // per-wave candidate ring (u16 entries): 63 left over + 2 x 64 pushed by one filter step
                                           // = 191 at most; a power of two, so that positions wrap with one v_and instead of
                                           // two compare / select pairs per push (4-cycle instructions, eight pushes per trip)
@@ -1367,6 +1370,10 @@ __device__ __forceinline__ void cand_filter_and_drain(const DevScene &S, const C
     };
     PT_PHASE(kPhFilter);
     const vec3 inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    // (Noting a lane's first two candidate records in registers while the filters run and pushing twice at the end of the
+    // loop instead of twice per record - a third candidate pushed on the spot - was built and measured: some lane of a wave
+    // nearly always grazes a plane (|d_a| < 1/64 makes it a candidate of both halves of that axis' record), so the "rare"
+    // third-candidate push runs in most trips on top of the two at the end: cornell 36.3 against 39.6 G bounces/s.)
     for (uint32_t p = 0; p < S.n_flat_pairs; ++p) {
         const FlatPairRec f = ld_uniform(S.flat_pairs + p);
         bool c0, c1;
@@ -1681,8 +1688,12 @@ __device__ __forceinline__ void shade_surface(const Params &F, const PathRay &in
 }
 
 // render_pixel's per-sample ray (mod.rs:805-843) for framebuffer index `pix`, sample `s`
+// PROBE: the kernel instance pt_ctx_radiance launches - every primary ray is FrameParams' fixed ray at depth depth0.  A
+// template parameter, not a branch on F.probe: the branch alone cost the frame kernels 1.3 % (registers around the two ray
+// makers; A/B on one GPU), and a frame never probes.
+template <bool PROBE = false>
 __device__ __forceinline__ PathRay primary_ray(const FrameParams &F, uint32_t pix, uint32_t s) {
-    if (F.probe) {  // wave-uniform (a kernel argument): pt_ctx_radiance's fixed ray, sample s of "pixel" pix
+    if (PROBE) {  // pt_ctx_radiance's fixed ray, sample s of "pixel" pix
         PathRay r;
         r.o = mk(F.probe_ox, F.probe_oy, F.probe_oz);
         r.d = mk(F.probe_dx, F.probe_dy, F.probe_dz);
@@ -1709,7 +1720,7 @@ __device__ __forceinline__ PathRay primary_ray(const FrameParams &F, uint32_t pi
     r.d = normalize(lens - sensor_pos);
     r.thr = mk(1.0f, 1.0f, 1.0f);
     r.pix = pix;
-    r.meta = pack_meta(s, F.depth0, 1u);
+    r.meta = pack_meta(s, 0u, 1u);  // radiance(&ray, 0, ..), mod.rs:844
     return r;
 }
 

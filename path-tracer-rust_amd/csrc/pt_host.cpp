@@ -561,10 +561,10 @@ bool flatten_scene(const pt_camera &cam, const pt_object *objs, uint32_t n_objs,
                 // The filter only judges rays with |d_a| >= kGrazing, for which |determinant| = |d_a| |N| >= |N| / 64
                 // (and >= 1e-4, mod.rs:571): the forward-error bound of the BVH boxes above with that determinant in
                 // place of 1e-4, plus the filter's own arithmetic (an approximate reciprocal and two fmas on
-                // distances up to 64 R).
+                // distances up to R / kGrazing).
                 const float e = 5.9604645e-8f;
                 const float det_min = std::fmax(1e-4f, n_min * kGrazing);
-                const float pad = 3.0f * (16.0f * e * L * L * (scene_R + L) / det_min) + 2048.0f * e * (scene_R + L) + 1e-5f;
+                const float pad = 3.0f * (16.0f * e * L * L * (scene_R + L) / det_min) + (32.0f / kGrazing) * e * (scene_R + L) + 1e-5f;
                 const bool usable = axis >= 0 && std::isfinite(pad) && std::isfinite(n_min) && n_min > 0.0f;
                 if (!usable) {
                     out.cand_pairs.push_back(cand_rec(i, pp));

@@ -98,6 +98,7 @@ __device__ __forceinline__ void load_ray_slice(const StreamSlice &q, uint32_t i,
 }
 
 // ------------------------------------------------------------------------------------------------
+template <bool PROBE>
 __global__ __launch_bounds__(kBlock) void k_generate(FrameParams F, RayQueue q, uint32_t *__restrict__ cnt0,
                                                      uint32_t cap, uint32_t s0, uint32_t s_here, uint32_t m) {
     // stream b = its pixels (stream_pixel) x samples [s0, s0+s_here); lane order: pixel fastest
@@ -108,8 +109,8 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams F, RayQueue q, 
     for (uint32_t g = tid; g < n; g += kBlock) {
         const uint32_t pl = stream_pixel(F.n_streams, b, g % mb);
         const uint32_t s = s0 + g / mb;
-        const PathRay r = primary_ray(F, global_pixel(F, pl), s);
-        store_ray(q, base + g, r.o, r.d, r.thr, pack_word(g % mb, g / mb, F.depth0, 1u));
+        const PathRay r = primary_ray<PROBE>(F, global_pixel(F, pl), s);
+        store_ray(q, base + g, r.o, r.d, r.thr, pack_word(g % mb, g / mb, PROBE ? F.depth0 : 0u, 1u));
     }
     if (tid == 0) cnt0[b] = n;
 }
@@ -194,6 +195,87 @@ __global__ __launch_bounds__(BVH ? kBlockBvh : kBlock, BVH ? 5 : 1) void k_inter
             }
         }
         if (n_park != 0u) walk(lane, lane < n_park);
+    }
+    if (tid == 0) blk_rays[b] += n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The stand-alone intersect step with the CANDIDATE SCAN of k_pass_cand (pt_device.h: "Candidate scan"; scenes without BVH
+// meshes): intersect_scene (mod.rs:631-659) for every ray of a stream, as its own kernel - 24 B of ray in, 8 B of hit
+// record out, nothing else: the kernel the north star's "HBM roofline of the intersect kernel" speaks of.  Per chunk of
+// 256 rays: origin and direction into the chunk's LDS slots, spheres exactly (first key), filters of the flat pair records,
+// candidates to the wave's ring, full batches of 64 exact tests as the ring fills; a ray's hit is written one chunk after
+// it was started, when every candidate of its chunk has been through a batch (the ring is first-in first-out).  The hit
+// record is HitRec's: (t, id) with id = DevScene.rank_id[rank of the key], -1 and t = +inf for a miss - bit for bit what
+// k_intersect<false> writes (test_pass_kernel_equals_separate_kernels).
+__host__ __device__ constexpr size_t intersect_cand_lds_bytes() { return (size_t)(kBlock / 64u) * kCandWaveBytes; }
+
+template <bool STAGED>
+__global__ __launch_bounds__(kBlock, 4) void k_intersect_cand(DevScene S, RayQueue q, float2 *__restrict__ hit,
+                                                              const uint32_t *__restrict__ cnt, uint32_t cap,
+                                                              unsigned long long *__restrict__ blk_rays) {
+    const uint32_t b = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t n = cnt[b];
+    if (n == 0u) return;  // (the whole workgroup)
+    CandLds cand;
+    {
+        char *wbase = reinterpret_cast<char *>(dyn_lds) + (size_t)(tid >> 6) * kCandWaveBytes;
+        cand.ray_a = reinterpret_cast<float4 *>(wbase);
+        cand.keys = reinterpret_cast<unsigned long long *>(wbase + 128u * 16u);
+        cand.ray_b = reinterpret_cast<float2 *>(wbase + 128u * 24u);
+        cand.queue = reinterpret_cast<uint16_t *>(wbase + 128u * 32u);
+        char *sbase = reinterpret_cast<char *>(dyn_lds) + intersect_cand_lds_bytes();
+        cand.staged = reinterpret_cast<const CandPairRec *>(sbase);
+        cand.surf = S.surf;
+        if (STAGED) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(S.cand_pairs);
+            uint4 *dst = reinterpret_cast<uint4 *>(sbase);
+            const uint32_t n_rows = S.n_cand_pairs * (uint32_t)(sizeof(CandPairRec) / 16u);
+            for (uint32_t k = tid; k < n_rows; k += kBlock) dst[k] = src[k];
+            __syncthreads();
+        }
+    }
+    const StreamSlice qin = slice_of(q, (size_t)b * cap);
+    float2 *const hit_b = hit + (size_t)b * cap;
+    CandRing ring;
+    ring.head = 0u;
+    ring.count = 0u;
+    const uint32_t n_chunks = (n + kBlock - 1u) / kBlock;
+    bool prev_valid = false;
+    for (uint32_t it = 0; it <= n_chunks; ++it) {  // uniform trip count; the last trip only finishes chunk n_chunks - 1
+        const uint32_t par = it & 1u;
+        const uint32_t i = it * kBlock + tid;
+        const bool cur_valid = it < n_chunks && i < n;
+        const uint32_t pending = ring.count;  // entries of chunk it - 1 still queued (< 64)
+        bool ran_batch = false;
+        if (it < n_chunks && it * kBlock + (tid & ~63u) < n) {  // (a wave without a ray of this chunk starts nothing)
+            vec3 o = mk(0.0f, 0.0f, 0.0f), d = o;
+            if (cur_valid) {
+                const float4 a = *reinterpret_cast<const float4 *>(qin.od0 + i * 16u);
+                const float2 c = *reinterpret_cast<const float2 *>(qin.od1 + i * 8u);
+                o = mk(a.x, a.y, a.z);
+                d = mk(a.w, c.x, c.y);
+            }
+            const uint32_t slot = (par << 6) | lane;
+            cand.ray_a[slot] = make_float4(o.x, o.y, o.z, d.x);
+            cand.ray_b[slot] = make_float2(d.y, d.z);
+            float bound;
+            const unsigned long long key0 = cand_spheres(S, o, d, &bound);
+            cand.keys[slot] = cur_valid ? key0 : kKeyMiss;
+            const uint32_t before = ring.head;
+            cand_filter_and_drain<STAGED>(S, cand, ring, lane, par, cur_valid, o, d, bound);
+            ran_batch = ring.head != before;
+        }
+        if (it > 0u) {
+            if (pending != 0u && !ran_batch) cand_batch<STAGED>(S, cand, ring, lane, ring.count);
+            if (prev_valid) {
+                const unsigned long long key = load_key(&cand.keys[((par ^ 1u) << 6) | lane]);
+                const uint32_t rank = (uint32_t)key;
+                const int32_t id = rank != 0xffffffffu ? (int32_t)S.rank_id[rank] : -1;
+                hit_b[(it - 1u) * kBlock + tid] = make_float2(__uint_as_float((uint32_t)(key >> 32)), __int_as_float(id));
+            }
+        }
+        prev_valid = cur_valid;
     }
     if (tid == 0) blk_rays[b] += n;
 }
@@ -321,7 +403,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, ShadeParams F, Ray
 // write and re-read of the primary rays, and it lets streams that are intersecting (VALU-bound) share a CU with
 // streams that are waiting on their queue loads.  The accumulators stay in LDS for the whole pass and are flushed
 // once.  Scenes with a BVH keep the three-kernel form (their intersect step wants 512-thread workgroups).
-template <bool DEFER>
+template <bool DEFER, bool PROBE>
 __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, RayQueue q0, RayQueue q1, uint32_t cap,
                                                  uint32_t s0, uint32_t s_here, uint32_t m,
                                                  unsigned long long *__restrict__ acc,
@@ -425,8 +507,8 @@ __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, R
             if (i < n) {
                 if (depth == 0u) {  // render_pixel's ray for (pixel i % mb of the stream, sample s0 + i / mb)
                     const uint32_t pj = i % mb, sj = i / mb;
-                    in = primary_ray(F, lds_pix[pj], s0 + sj);
-                    word = pack_word(pj, sj, F.depth0, 1u);
+                    in = primary_ray<PROBE>(F, lds_pix[pj], s0 + sj);
+                    word = pack_word(pj, sj, PROBE ? F.depth0 : 0u, 1u);
                 } else {
                     const float4 a = *reinterpret_cast<const float4 *>(qin.od0 + i * 16u);
                     const float4 tp = *reinterpret_cast<const float4 *>(qin.tp + i * 16u);
@@ -525,7 +607,7 @@ static_assert(kCandParkBytes % 16u == 0u && kCandWalkKeyBytes % 16u == 0u, "per-
 
 // (The workgroup's own copy of the nodes in LDS, in front of the stacks, was tried: mesh.json's 141 nodes are 9 KB, which
 // leaves room for three workgroups per CU instead of four - 16.1 against 17.8 G bounces/s.)
-template <bool STAGED, bool DEFER, bool BVH>
+template <bool STAGED, bool DEFER, bool BVH, bool PROBE>
 __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams F, RayQueue q0, RayQueue q1, uint32_t cap,
                                                          uint32_t s0, uint32_t s_here, uint32_t m,
                                                          unsigned long long *__restrict__ acc,
@@ -680,8 +762,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
             PathRay in;
             if (level == 0u) {
                 const uint32_t pj = i % mb, sj = i / mb;
-                in = primary_ray(F, lds_pix[pj], s0 + sj);
-                word = pack_word(pj, sj, F.depth0, 1u);
+                in = primary_ray<PROBE>(F, lds_pix[pj], s0 + sj);
+                word = pack_word(pj, sj, PROBE ? F.depth0 : 0u, 1u);
             } else {
                 load_ray_slice(qin, i, in.o, in.d, in.thr, word);
             }
@@ -729,17 +811,17 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
             uint32_t word = 0;
             const uint32_t pending = ring.count;  // entries of chunk it - 1 still queued (< 64)
             bool ran_batch = false;
-            // (a wave none of whose lanes holds a ray of this chunk - the partial last chunk of a level - starts nothing: its
-            // slots are never read, prev_valid will be false for every lane)
-            if (it < n_chunks && it * kBlock + (tid & ~63u) < n) {
+            // (Letting a wave without a ray of this chunk - the partial last chunk of a level - skip the start of the trip was
+            // measured: 38.9 against 39.3 G bounces/s, the extra branch costs more than the skipped work.)
+            if (it < n_chunks) {
                 PT_PHASE(depth == 0u ? kPhPrimary : kPhLoad);
                 PathRay in;
                 in.o = in.d = in.thr = mk(0.0f, 0.0f, 0.0f);
                 if (cur_valid) {
                     if (depth == 0u) {  // render_pixel's ray for (pixel i % mb of the stream, sample s0 + i / mb)
                         const uint32_t pj = i % mb, sj = i / mb;
-                        in = primary_ray(F, lds_pix[pj], s0 + sj);
-                        word = pack_word(pj, sj, F.depth0, 1u);
+                        in = primary_ray<PROBE>(F, lds_pix[pj], s0 + sj);
+                        word = pack_word(pj, sj, PROBE ? F.depth0 : 0u, 1u);
                     } else {
                         load_ray_slice(qin, i, in.o, in.d, in.thr, word);
                     }
@@ -896,6 +978,7 @@ __host__ __device__ inline size_t pass_bvh_lds_bytes(const DevScene &S, uint32_t
     return pass_bvh_leaf_offset(S, m) + (size_t)(kBlock / 64u) * (64u * 8u + kLeafListCap * 4u);
 }
 
+template <bool PROBE>
 __global__ __launch_bounds__(kBlock, 4) void k_pass_bvh(DevScene S, FrameParams F, RayQueue q0, RayQueue q1, uint32_t cap,
                                                         uint32_t s0, uint32_t s_here, uint32_t m,
                                                         unsigned long long *__restrict__ acc,
@@ -941,8 +1024,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_bvh(DevScene S, FrameParams 
     __syncthreads();           // lds_pix
     for (uint32_t g = tid; g < n; g += kBlock) {  // level 0: render_pixel's rays (pixel g % mb, sample s0 + g / mb)
         const uint32_t pj = g % mb, sj = g / mb;
-        const PathRay r = primary_ray(F, lds_pix[pj], s0 + sj);
-        store_ray(q0, base + g, r.o, r.d, r.thr, pack_word(pj, sj, F.depth0, 1u));
+        const PathRay r = primary_ray<PROBE>(F, lds_pix[pj], s0 + sj);
+        store_ray(q0, base + g, r.o, r.d, r.thr, pack_word(pj, sj, PROBE ? F.depth0 : 0u, 1u));
     }
     uint32_t n_park = 0;  // wave-uniform
     StreamSlice qin{}, qout{};
@@ -1102,7 +1185,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter_chunks(const float *__restri
 // The refract split (mod.rs:775-786) pushes the transmitted ray on a two-entry stack in registers.
 // One launch = one ROUND: the samples [s_begin, s_end) of every pixel of the call; item = (pixel, part of the round):
 // part k of `n_split` walks the samples s_begin + k*lane_spp ... (< s_end).
-template <bool BVH>
+template <bool BVH, bool PROBE>
 __global__ __launch_bounds__(kBlock) void k_mega(DevScene S, FrameParams F, unsigned long long *__restrict__ acc,
                                                  uint32_t s_begin, uint32_t s_end, uint32_t lane_spp, uint32_t n_split,
                                                  unsigned long long *__restrict__ total_rays) {
@@ -1138,7 +1221,7 @@ __global__ __launch_bounds__(kBlock) void k_mega(DevScene S, FrameParams F, unsi
                     sp = 0;
                     active = true;
                 } else if (s < s_stop) {
-                    cur = primary_ray(F, global_pixel(F, pl), s);
+                    cur = primary_ray<PROBE>(F, global_pixel(F, pl), s);
                     ++s;
                     active = true;
                 }
@@ -1383,15 +1466,27 @@ __global__ __launch_bounds__(256) void k_numerics_sweep(unsigned long long *__re
 // ------------------------------------------------------------------------------------------------ launchers
 void launch_generate(hipStream_t st, uint32_t K, const FrameParams &F, const RayQueue &q, uint32_t *cnt0,
                      uint32_t cap, uint32_t s0, uint32_t s_here, uint32_t m) {
-    hipLaunchKernelGGL(k_generate, dim3(K), dim3(kBlock), 0, st, F, q, cnt0, cap, s0, s_here, m);
+    if (F.probe)
+        hipLaunchKernelGGL(k_generate<true>, dim3(K), dim3(kBlock), 0, st, F, q, cnt0, cap, s0, s_here, m);
+    else
+        hipLaunchKernelGGL(k_generate<false>, dim3(K), dim3(kBlock), 0, st, F, q, cnt0, cap, s0, s_here, m);
 }
 void launch_intersect(hipStream_t st, uint32_t K, const DevScene &S, const RayQueue &q, float2 *hit,
                       const uint32_t *cnt, uint32_t cap, unsigned long long *blk_rays) {
-    if (S.n_bvh_nodes != 0u)
+    if (S.n_bvh_nodes != 0u) {
         hipLaunchKernelGGL(k_intersect<true>, dim3(K), dim3(kBlockBvh),
                            bvh_park_offset(S, kBlockBvh) + bvh_park_bytes(kBlockBvh), st, S, q, hit, cnt, cap, blk_rays);
-    else
+    } else if (S.cand_scan) {  // the candidate scan (PT_CAND_SCAN=0 / PT_FLAG_NO_BVH: the every-triangle scan below)
+        const size_t rec = (size_t)S.n_cand_pairs * sizeof(CandPairRec);
+        if (intersect_cand_lds_bytes() + rec <= 40u * 1024u)
+            hipLaunchKernelGGL(k_intersect_cand<true>, dim3(K), dim3(kBlock), intersect_cand_lds_bytes() + rec, st, S, q, hit, cnt,
+                               cap, blk_rays);
+        else
+            hipLaunchKernelGGL(k_intersect_cand<false>, dim3(K), dim3(kBlock), intersect_cand_lds_bytes(), st, S, q, hit, cnt, cap,
+                               blk_rays);
+    } else {
         hipLaunchKernelGGL(k_intersect<false>, dim3(K), dim3(kBlock), 0, st, S, q, hit, cnt, cap, blk_rays);
+    }
 }
 void launch_shade(hipStream_t st, uint32_t K, const DevScene &S, const FrameParams &F, const RayQueue &qin,
                   const RayQueue &qout, const float2 *hit, const uint32_t *cnt_in, uint32_t *cnt_out, uint32_t cap,
@@ -1447,8 +1542,15 @@ hipError_t launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const Fram
         // (more than 64 KB of dynamic LDS - wide deep trees with hundreds of pixels per stream - has to be asked for)
 #define PT_LAUNCH_CAND(ST, DF, BV)                                                                                     \
     do {                                                                                                               \
+        if (F.probe)                                                                                                   \
+            PT_LAUNCH_CAND2(ST, DF, BV, true);                                                                         \
+        else                                                                                                           \
+            PT_LAUNCH_CAND2(ST, DF, BV, false);                                                                        \
+    } while (0)
+#define PT_LAUNCH_CAND2(ST, DF, BV, PR)                                                                                   \
+    do {                                                                                                               \
         if (lds > 64u * 1024u) {                                                                                       \
-            const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pass_cand<ST, DF, BV>),         \
+            const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pass_cand<ST, DF, BV, PR>),     \
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
             if (ea != hipSuccess) {                                                                                    \
                 set_error("k_pass_cand needs " + std::to_string(lds) + " bytes of LDS per workgroup for this scene: " +  \
@@ -1456,7 +1558,7 @@ hipError_t launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const Fram
                 return ea;                                                                                             \
             }                                                                                                          \
         }                                                                                                              \
-        hipLaunchKernelGGL((k_pass_cand<ST, DF, BV>), dim3(K), dim3(kBlock), lds, st, S2, F, q0, q1, cap, s0, s_here, m, acc, blk_rays, flags); \
+        hipLaunchKernelGGL((k_pass_cand<ST, DF, BV, PR>), dim3(K), dim3(kBlock), lds, st, S2, F, q0, q1, cap, s0, s_here, m, acc, blk_rays, flags); \
     } while (0)
         if (bvh && staged)
             PT_LAUNCH_CAND(true, false, true);
@@ -1471,21 +1573,31 @@ hipError_t launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const Fram
         else
             PT_LAUNCH_CAND(false, false, false);
 #undef PT_LAUNCH_CAND
+#undef PT_LAUNCH_CAND2
         return hipSuccess;
     }
-    if (lds_defer <= 32u * 1024u)
-        hipLaunchKernelGGL(k_pass<true>, dim3(K), dim3(kBlock), lds_defer, st, S, F, q0, q1, cap, s0, s_here, m, acc,
-                           blk_rays, flags);
-    else
-        hipLaunchKernelGGL(k_pass<false>, dim3(K), dim3(kBlock), lds_plain, st, S, F, q0, q1, cap, s0, s_here, m, acc,
-                           blk_rays, flags);
+    if (lds_defer <= 32u * 1024u) {
+        if (F.probe)
+            hipLaunchKernelGGL((k_pass<true, true>), dim3(K), dim3(kBlock), lds_defer, st, S, F, q0, q1, cap, s0, s_here, m, acc, blk_rays, flags);
+        else
+            hipLaunchKernelGGL((k_pass<true, false>), dim3(K), dim3(kBlock), lds_defer, st, S, F, q0, q1, cap, s0, s_here, m, acc, blk_rays, flags);
+    } else {
+        if (F.probe)
+            hipLaunchKernelGGL((k_pass<false, true>), dim3(K), dim3(kBlock), lds_plain, st, S, F, q0, q1, cap, s0, s_here, m, acc, blk_rays, flags);
+        else
+            hipLaunchKernelGGL((k_pass<false, false>), dim3(K), dim3(kBlock), lds_plain, st, S, F, q0, q1, cap, s0, s_here, m, acc, blk_rays, flags);
+    }
     return hipSuccess;
 }
 void launch_pass_bvh(hipStream_t st, uint32_t K, const DevScene &S, const FrameParams &F, const RayQueue &q0,
                      const RayQueue &q1, uint32_t cap, uint32_t s0, uint32_t s_here, uint32_t m, unsigned long long *acc,
                      unsigned long long *blk_rays, uint32_t *flags) {
-    hipLaunchKernelGGL(k_pass_bvh, dim3(K), dim3(kBlock), pass_bvh_lds_bytes(S, m), st, S, F, q0, q1, cap, s0, s_here, m,
-                       acc, blk_rays, flags);
+    if (F.probe)
+        hipLaunchKernelGGL(k_pass_bvh<true>, dim3(K), dim3(kBlock), pass_bvh_lds_bytes(S, m), st, S, F, q0, q1, cap, s0, s_here, m,
+                           acc, blk_rays, flags);
+    else
+        hipLaunchKernelGGL(k_pass_bvh<false>, dim3(K), dim3(kBlock), pass_bvh_lds_bytes(S, m), st, S, F, q0, q1, cap, s0, s_here, m,
+                           acc, blk_rays, flags);
 }
 void launch_scatter_chunks(hipStream_t st, const float *src, float *dst, uint32_t npix, uint32_t C, uint32_t n,
                            uint32_t j) {
@@ -1498,12 +1610,15 @@ void launch_resolve(hipStream_t st, const unsigned long long *acc, float *out, u
 }
 void launch_mega(hipStream_t st, uint32_t grid, const DevScene &S, const FrameParams &F, unsigned long long *acc,
                  uint32_t s_begin, uint32_t s_end, uint32_t lane_spp, uint32_t n_split, unsigned long long *total_rays) {
-    if (S.n_bvh_nodes != 0u)
-        hipLaunchKernelGGL(k_mega<true>, dim3(grid), dim3(kBlock), bvh_lds_bytes(S, kBlock), st, S, F, acc, s_begin, s_end,
-                           lane_spp, n_split, total_rays);
+    const size_t lds = S.n_bvh_nodes != 0u ? bvh_lds_bytes(S, kBlock) : 0u;
+    if (S.n_bvh_nodes != 0u && F.probe)
+        hipLaunchKernelGGL((k_mega<true, true>), dim3(grid), dim3(kBlock), lds, st, S, F, acc, s_begin, s_end, lane_spp, n_split, total_rays);
+    else if (S.n_bvh_nodes != 0u)
+        hipLaunchKernelGGL((k_mega<true, false>), dim3(grid), dim3(kBlock), lds, st, S, F, acc, s_begin, s_end, lane_spp, n_split, total_rays);
+    else if (F.probe)
+        hipLaunchKernelGGL((k_mega<false, true>), dim3(grid), dim3(kBlock), lds, st, S, F, acc, s_begin, s_end, lane_spp, n_split, total_rays);
     else
-        hipLaunchKernelGGL(k_mega<false>, dim3(grid), dim3(kBlock), 0, st, S, F, acc, s_begin, s_end, lane_spp, n_split,
-                           total_rays);
+        hipLaunchKernelGGL((k_mega<false, false>), dim3(grid), dim3(kBlock), lds, st, S, F, acc, s_begin, s_end, lane_spp, n_split, total_rays);
 }
 void launch_query(hipStream_t st, const DevScene &S, const float *o, const float *d, uint32_t n, float *t,
                   int32_t *object_id, int32_t *tri_id, float *x, float *nrm) {

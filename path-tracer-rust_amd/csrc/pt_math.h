@@ -12,7 +12,7 @@
 //                                              bit-identical to glibc 2.35 on all 2^24 reachable
 //                                              arguments (tests/test_oracle.py)
 //   powi(2), powi(5) (mod.rs:416,741,754)      x*x, x*((x*x)*(x*x))
-// rand01() itself (ThreadRng, OS seeded) is replaced by Philox4x32-10 keyed per
+// rand01() itself (ThreadRng, OS seeded) is replaced by Philox4x32-7 keyed per
 // (seed, pixel, sample, branch, depth) so that CPU and GPU draw the same numbers in any order.
 #pragma once
 
@@ -90,14 +90,21 @@ PT_HD vec3 normalize(vec3 a) { return a * f_rcp(length(a)); }
 // ---- rand 0.8.5: 24 high bits of a u32 -> [0,1)
 PT_HD float unit_f32(uint32_t u) { return (float)(u >> 8) * (1.0f / 16777216.0f); }
 
-// ---- Philox4x32-10 (Salmon et al., SC'11); KATs in tests/test_oracle.py
+// ---- Philox4x32-R (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11); Random123's known-answer vectors
+// for 7 and 10 rounds in tests/test_oracle.py.  The path draws with SEVEN rounds (Random123's philox4x32_R(7, ..): the
+// fewest rounds the paper reports as Crush-resistant - it passes BigCrush - and the count its authors recommend where speed
+// matters; ten is their default with a safety margin).  rand01() of the reference is an OS-seeded ThreadRng (mod.rs:47-55):
+// which generator stands in for it is this build's own contract, and the generator was 5 % of k_pass_cand's time with ten
+// rounds (profiles/r03_k_pass_cand_phase_budget.json; seven: +1.9 % frame rate, A/B on one GPU).
 struct u32x4 {
     uint32_t a, b, c, d;
 };
+constexpr int kPhiloxRounds = 7;
 
-PT_HD u32x4 philox4x32_10(u32x4 ctr, uint32_t k0, uint32_t k1) {
+template <int ROUNDS>
+PT_HD u32x4 philox4x32(u32x4 ctr, uint32_t k0, uint32_t k1) {
 #pragma unroll
-    for (int round = 0; round < 10; ++round) {
+    for (int round = 0; round < ROUNDS; ++round) {
         // one 32x32->64 multiply per word pair (v_mad_u64_u32 on gfx950) instead of separate mul_hi / mul_lo
         const uint64_t p0 = (uint64_t)0xD2511F53u * ctr.a, p1 = (uint64_t)0xCD9E8D57u * ctr.c;
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
@@ -124,7 +131,7 @@ PT_HD u32x4 draw_block(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t 
     c.b = sample;
     c.c = tag;
     c.d = 0u;
-    return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return philox4x32<kPhiloxRounds>(c, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 
 // ---- sinf / cosf for |y| < 120: glibc (ARM optimized-routines) algorithm, evaluated in binary64

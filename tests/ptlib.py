@@ -98,6 +98,7 @@ def oracle():
     L.pto_cosf.restype = C.c_float
     L.pto_sincos_vs_libm.argtypes = [C.c_uint32, C.c_uint32, u64p, u64p]
     L.pto_philox4x32_10.argtypes = [u32p, u32p, u32p]
+    L.pto_philox4x32_7.argtypes = [u32p, u32p, u32p]
     L.pto_u32_to_unit.argtypes = [C.c_uint32]
     L.pto_u32_to_unit.restype = C.c_float
     L.pto_draw4.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, fp]

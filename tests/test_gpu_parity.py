@@ -98,7 +98,7 @@ def test_device_numerics_contract(gpu):
     out = (C.c_uint32 * 4)()
     for i in list(range(64)) + [n - 1]:
         ctr = (C.c_uint32 * 4)(i, int(x[i:i + 1].view(np.uint32)[0]), ((i << 8) | (i & 15)) & 0xffffffff, 0)
-        O.pto_philox4x32_10(ctr, (C.c_uint32 * 2)(0x89abcdef, 0x01234567), out)
+        O.pto_philox4x32_7(ctr, (C.c_uint32 * 2)(0x89abcdef, 0x01234567), out)
         assert list(out) == list(ph[4 * i:4 * i + 4])
 
 
@@ -770,6 +770,10 @@ def test_pass_kernel_equals_separate_kernels(gpu, sid):
         assert sa.ray_bounces == sb.ray_bounces and sa.samples == sb.samples and sa.passes == sb.passes
         assert sa.intersect_launches == sa.passes and sb.intersect_launches == 12 * sb.passes  # really two paths
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (sid, w, h, spp)
+        # ... and the stand-alone intersect step in both its forms: candidate scan (k_intersect_cand, above) and every
+        # triangle per ray (k_intersect<false>: PT_FLAG_NO_BVH)
+        c, sc3 = _render_flags(gpu, sc, w, h, spp, 11, PT_FLAG_SEPARATE_KERNELS | ptlib.FLAG_NO_BVH, rpp, chunks)
+        assert sc3.ray_bounces == sa.ray_bounces and np.array_equal(a.view(np.uint32), c.view(np.uint32)), (sid, w, h, spp)
 
 
 def test_pass_kernel_full_size(gpu):
@@ -1350,7 +1354,8 @@ import kats_shading
 
 FLAG_SEPARATE_KERNELS = 2
 # every device path: (backend, flags, the kernel it must report for scenes without BVH meshes)
-DEVICE_PATHS = [(0, 0, b"k_pass_cand"), (0, ptlib.FLAG_NO_BVH, b"k_pass"), (0, FLAG_SEPARATE_KERNELS, b"k_intersect"),
+DEVICE_PATHS = [(0, 0, b"k_pass_cand"), (0, ptlib.FLAG_NO_BVH, b"k_pass"), (0, FLAG_SEPARATE_KERNELS, b"k_intersect_cand"),
+                (0, FLAG_SEPARATE_KERNELS | ptlib.FLAG_NO_BVH, b"k_intersect"),
                 (1, 0, None)]
 
 
@@ -1434,7 +1439,9 @@ def test_reference_radiance_test_run_literally(gpu):
     assert ref[0] > 0.3
     for backend, flags, _ in DEVICE_PATHS:
         got, st = gpu_radiance(gpu, o, d, 0, 10000, 1, 0, backend, flags)
-        assert got[0] > 0.3 and abs(got[0] - 50.0 / 144.0) < 0.03, got
+        # (a sample is 50 with probability 1/144, else 0: the mean of 10 000 has a standard deviation of 0.042 - the
+        # reference's `> 0.3` holds for this seed; three standard deviations around the analytic value hold for any)
+        assert got[0] > 0.3 and abs(got[0] - 50.0 / 144.0) < 0.125, got
         assert got[1] == 0.0 and got[2] == 0.0
         assert st.ray_bounces == cnt.ray_bounces
         assert abs(got[0] - ref[0]) <= 1e-4, (got, ref)

@@ -89,6 +89,31 @@ def test_rust_shim_mirrors_the_header():
         r_val = int(re.search(r"pub const %s: i32 = (-?\d+);" % name, rust).group(1))
         assert c_val == r_val
     assert len(re.findall(r"pub fn pt_render\(", rust)) == 1 and "pub fn flatten(" in rust
+    # every function the shim binds is declared in the header with the same number of parameters, in the same order by
+    # kind (pointer / integer / float), and the preview path uses the resident form
+    ext = re.search(r'extern "C" \{(.*?)\n\}', rust, flags=re.S).group(1)
+    bound = re.findall(r"pub fn (\w+)\((.*?)\)\s*(?:->\s*([\w\s\*]+))?;", ext, flags=re.S)
+    assert {"pt_ctx_create", "pt_ctx_destroy", "pt_ctx_set_scene", "pt_ctx_render", "pt_ctx_snapshot", "pt_device_malloc",
+            "pt_device_free", "pt_device_download", "pt_render"} <= {b[0] for b in bound}
+
+    def kind_rust(t):
+        t = t.strip()
+        return "p" if t.startswith("*") or t.startswith("Option<") else ("f" if t in ("f32", "f64") else "i")
+
+    def kind_c(t):
+        t = t.strip()
+        return "p" if "*" in t or "[" in t or t.startswith("pt_progress_fn") else ("f" if t.split()[0] in ("float", "double") else "i")
+
+    for fname, params, _ in bound:
+        m = re.search(r"\b%s\((.*?)\);" % fname, header, flags=re.S)
+        assert m, fname + " is not declared in include/ptrace.h"
+        c_params = [q for q in m.group(1).split(",") if q.strip() and q.strip() != "void"]
+        r_params = [q.split(":", 1)[1] for q in params.split(",") if ":" in q]
+        assert [kind_c(q) for q in c_params] == [kind_rust(q) for q in r_params], (fname, c_params, r_params)
+    body = rust[rust.index("pub fn render_pixels_hip"):]
+    for call in ("pt_ctx_create", "pt_ctx_set_scene", "pt_ctx_render", "pt_device_download", "pt_ctx_destroy"):
+        assert call + "(" in body, call
+    assert "pt_ctx_snapshot(" in rust[rust.index('extern "C" fn on_progress'):rust.index("pub fn render_pixels_hip")]
 
 FLATTEN_SRC = r"""
 #include <cstdio>

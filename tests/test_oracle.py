@@ -117,11 +117,31 @@ PHILOX_KATS = [  # Random123 kat_vectors, philox4x32 10 rounds: counter, key, ex
 ]
 
 
+PHILOX7_KATS = [  # Random123 kat_vectors, philox4x32 7 rounds (the rounds the RNG contract draws with)
+    ([0, 0, 0, 0], [0, 0], [0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48]),
+    ([0xffffffff] * 4, [0xffffffff] * 2, [0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662]),
+    ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+     [0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a]),
+]
+
+
 @pytest.mark.parametrize("ctr,key,want", PHILOX_KATS)
 def test_philox_kat(ctr, key, want):
     out = (C.c_uint32 * 4)()
     L.pto_philox4x32_10((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), out)
     assert list(out) == want
+
+
+@pytest.mark.parametrize("ctr,key,want", PHILOX7_KATS)
+def test_philox7_kat_and_the_draws_use_it(ctr, key, want):
+    out = (C.c_uint32 * 4)()
+    L.pto_philox4x32_7((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), out)
+    assert list(out) == want
+    # pto_draw4 (what radiance() and render_pixel draw from): the same words through rand 0.8.5's u32 -> f32 map
+    u = (C.c_float * 4)()
+    L.pto_draw4(key[0] | (key[1] << 32), ctr[0], ctr[1], ctr[2], u)
+    if ctr[3] == 0:
+        assert list(u) == [L.pto_u32_to_unit(w) for w in want]
 
 
 def test_u32_to_unit():
@@ -373,7 +393,7 @@ def test_oracle_reproduces_golden_numerics():
     out = np.zeros(4, np.uint32)
     for ctr, key, want in zip(g["philox_ctr"], g["philox_key"], g["philox_out"]):
         ctr, key = np.ascontiguousarray(ctr), np.ascontiguousarray(key)
-        O.pto_philox4x32_10(ctr.ctypes.data_as(ptlib.u32p), key.ctypes.data_as(ptlib.u32p), out.ctypes.data_as(ptlib.u32p))
+        O.pto_philox4x32_7(ctr.ctypes.data_as(ptlib.u32p), key.ctypes.data_as(ptlib.u32p), out.ctypes.data_as(ptlib.u32p))
         assert np.array_equal(out, want)
     gi = np.array([O.pto_to_int_with_gamma_correction(float(v)) for v in g["gamma_x"]], np.uint32)
     assert np.array_equal(gi, g["gamma_int"])

@@ -6,7 +6,7 @@ built in this image, so these vectors pin the restatement and everything checked
 
 Per scene: a small frame (48x32 @ 8 spp, seed 7) with its ray-bounce / sample counters, and the first rays the path
 tracer casts for it with the intersection result of each (distance, object, triangle, hit point, normal).
-Plus the RNG contract: Philox4x32-10 words, sin/cos on arguments of the 2*pi*k/2^24 lattice, gamma integers.
+Plus the RNG contract: Philox4x32-7 words, sin/cos on arguments of the 2*pi*k/2^24 lattice, gamma integers.
 tests/test_oracle.py checks that the oracle still reproduces these bits; tests/test_gpu_parity.py checks the HIP
 path against them (decisions bit-exact, images within 1e-4)."""
 import ctypes as C
@@ -59,7 +59,7 @@ def numerics_vectors():
     key = rng.integers(0, 1 << 32, size=(256, 2), dtype=np.uint64).astype(np.uint32)
     out = np.zeros((256, 4), np.uint32)
     for i in range(256):
-        O.pto_philox4x32_10(ctr[i].ctypes.data_as(ptlib.u32p), key[i].ctypes.data_as(ptlib.u32p),
+        O.pto_philox4x32_7(ctr[i].ctypes.data_as(ptlib.u32p), key[i].ctypes.data_as(ptlib.u32p),
                             out[i].ctypes.data_as(ptlib.u32p))
     g = np.linspace(0.0, 1.0, 513, dtype=np.float32)
     gi = np.array([O.pto_to_int_with_gamma_correction(float(v)) for v in g], np.uint32)
