@@ -1240,24 +1240,27 @@ struct CandRing {
     uint32_t head, count;
 };
 
+// The verdicts are WAVE MASKS, not per-lane booleans: every compare lands in an SGPR pair anyway, and combining the pairs
+// with scalar ands / ors keeps the VALU out of it - a ballot of a boolean that is itself a combination of compares costs a
+// v_cndmask and a v_cmp to get back to the mask the compares already were (16 issue cycles per record).
 template <int AXIS>
-__device__ __forceinline__ void filter_flat(const FlatPairRec &f, vec3 o, vec3 d, vec3 inv, float bound, bool *c0, bool *c1) {
+__device__ __forceinline__ void filter_flat(const FlatPairRec &f, vec3 o, vec3 d, vec3 inv, float bound, uint64_t valid_m,
+                                            uint64_t graze, uint64_t *m0, uint64_t *m1) {
     const float oa = AXIS == 0 ? o.x : (AXIS == 1 ? o.y : o.z), ob = AXIS == 0 ? o.y : (AXIS == 1 ? o.z : o.x),
                 oc = AXIS == 0 ? o.z : (AXIS == 1 ? o.x : o.y);
-    const float da = AXIS == 0 ? d.x : (AXIS == 1 ? d.y : d.z), db = AXIS == 0 ? d.y : (AXIS == 1 ? d.z : d.x),
-                dc = AXIS == 0 ? d.z : (AXIS == 1 ? d.x : d.y);
+    const float db = AXIS == 0 ? d.y : (AXIS == 1 ? d.z : d.x), dc = AXIS == 0 ? d.z : (AXIS == 1 ? d.x : d.y);
     const float ia = AXIS == 0 ? inv.x : (AXIS == 1 ? inv.y : inv.z);
     const f32x2 t2 = (ld2(f.pc) - splat2(oa)) * splat2(ia);  // distance to the plane (approximate reciprocal)
     const f32x2 yb = __builtin_elementwise_fma(splat2(db), t2, splat2(ob)) - ld2(f.cb);
     const f32x2 zc = __builtin_elementwise_fma(splat2(dc), t2, splat2(oc)) - ld2(f.cc);
-    const bool graze = !(f_abs(da) >= kGrazing);  // also when da is NaN
     const f32x2 lim = splat2(bound) + ld2(f.tpad);
-    bool in[2];
+    uint64_t in[2];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
-        in[hf] = (int)(f_abs(yb[hf]) <= f.hb[hf]) & (int)(f_abs(zc[hf]) <= f.hc[hf]) & (int)(t2[hf] >= -f.tpad[hf]) & (int)(t2[hf] <= lim[hf]);
-    *c0 = (graze | in[0]) & (f.pair[0] != kNoPair);
-    *c1 = (graze | in[1]) & (f.pair[1] != kNoPair);
+        in[hf] = __builtin_amdgcn_ballot_w64(f_abs(yb[hf]) <= f.hb[hf]) & __builtin_amdgcn_ballot_w64(f_abs(zc[hf]) <= f.hc[hf]) &
+                 __builtin_amdgcn_ballot_w64(t2[hf] >= -f.tpad[hf]) & __builtin_amdgcn_ballot_w64(t2[hf] <= lim[hf]);
+    *m0 = f.pair[0] != kNoPair ? ((graze | in[0]) & valid_m) : 0ull;
+    *m1 = f.pair[1] != kNoPair ? ((graze | in[1]) & valid_m) : 0ull;
 }
 
 // intersect_sphere against the scene's spheres (mod.rs:412-427), two per record, in visiting order (strict '<' keeps
@@ -1343,17 +1346,16 @@ __device__ __forceinline__ void cand_filter_and_drain(const DevScene &S, const C
     // bits per lane and writing the set bits to the ring one per lane at a time - fewer ballot / prefix rounds when every
     // lane has one or two candidates - was tried: the rounds follow the lane with the most candidates; cornell 36.8
     // against 37.5 G bounces/s.)
-    auto push2 = [&](bool c0, uint32_t q0, bool c1, uint32_t q1) {
-        const uint64_t m0 = __builtin_amdgcn_ballot_w64(c0), m1 = __builtin_amdgcn_ballot_w64(c1);
+    auto push2 = [&](uint64_t m0, uint32_t q0, uint64_t m1, uint32_t q1) {  // the lanes of m0 push record q0, those of m1 q1
         if ((m0 | m1) == 0ull) return;
         const uint32_t n0 = (uint32_t)__builtin_popcountll(m0);
         const uint32_t base = R.head + R.count;
         const uint32_t me = lane | (par << 6);
-        if (c0) {
+        if (__builtin_amdgcn_inverse_ballot_w64(m0)) {
             const uint32_t at = (base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))) & (kCandQueueCap - 1u);
             L.queue[at] = (uint16_t)(me | (q0 << 7));
         }
-        if (c1) {
+        if (__builtin_amdgcn_inverse_ballot_w64(m1)) {
             const uint32_t at = (base + n0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u))) & (kCandQueueCap - 1u);
             L.queue[at] = (uint16_t)(me | (q1 << 7));
         }
@@ -1374,20 +1376,24 @@ __device__ __forceinline__ void cand_filter_and_drain(const DevScene &S, const C
     // loop instead of twice per record - a third candidate pushed on the spot - was built and measured: some lane of a wave
     // nearly always grazes a plane (|d_a| < 1/64 makes it a candidate of both halves of that axis' record), so the "rare"
     // third-candidate push runs in most trips on top of the two at the end: cornell 36.3 against 39.6 G bounces/s.)
+    const uint64_t valid_m = __builtin_amdgcn_ballot_w64(valid);
+    // rays that graze the planes of an axis (|d_a| < kGrazing, or NaN): not judged by the filters of that axis
+    const uint64_t gz_x = __builtin_amdgcn_ballot_w64(!(f_abs(d.x) >= kGrazing)), gz_y = __builtin_amdgcn_ballot_w64(!(f_abs(d.y) >= kGrazing)),
+                   gz_z = __builtin_amdgcn_ballot_w64(!(f_abs(d.z) >= kGrazing));
     for (uint32_t p = 0; p < S.n_flat_pairs; ++p) {
         const FlatPairRec f = ld_uniform(S.flat_pairs + p);
-        bool c0, c1;
+        uint64_t m0, m1;
         if (f.axis == 0u)
-            filter_flat<0>(f, o, d, inv, bound, &c0, &c1);
+            filter_flat<0>(f, o, d, inv, bound, valid_m, gz_x, &m0, &m1);
         else if (f.axis == 1u)
-            filter_flat<1>(f, o, d, inv, bound, &c0, &c1);
+            filter_flat<1>(f, o, d, inv, bound, valid_m, gz_y, &m0, &m1);
         else
-            filter_flat<2>(f, o, d, inv, bound, &c0, &c1);
-        push2(valid & c0, f.pair[0], valid & c1, f.pair[1]);
+            filter_flat<2>(f, o, d, inv, bound, valid_m, gz_z, &m0, &m1);
+        push2(m0, f.pair[0], m1, f.pair[1]);
         drain();
     }
     for (uint32_t q = 0; q < S.n_other_pairs; ++q) {  // records without a filter: a candidate for every ray
-        push2(valid, q, false, 0u);
+        push2(valid_m, q, 0ull, 0u);
         drain();
     }
 }
