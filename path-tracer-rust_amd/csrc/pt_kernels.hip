@@ -798,6 +798,13 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
         // chunk trips' lanes (profiles/r03_k_pass_cand_phase_budget.json), but every carried ray lengthens its stream by a
         // level, and the extra, nearly empty levels at the end of a stream cost what the full chunks saved: cornell 39.3
         // against 39.6 G bounces/s, mesh.json 21.0 against 22.4; same images.)
+        // (So was handing the level out in chunks of 64 rays that a wave takes from an LDS counter when it is done with one,
+        // instead of a fixed quarter of each 256-ray chunk per wave - the four waves then reach the level's barrier together,
+        // where they wait 3.9 % of their lifetime on cornell and 7.6 % on mesh.json: cornell 39.7 against 40.5, mesh.json 21.6
+        // against 22.6.  And five waves per SIMD: the kernel fits 96 VGPRs with 3 spilled values, but the workgroup's LDS
+        // - 39.5 KB, 18 KB of it the glass-deferral buffers - allows four workgroups per CU; without deferral five waves beat
+        // four, 40.7 against 39.5, but not four with deferral, 40.3; with deferral in 32 KB - 64 entries of 44 bytes - the
+        // kernel spills 8 values in the loop: 37.5.)
         const uint32_t n_chunks = (n + kBlock - 1u) / kBlock;
         total += n;
         vec3 prev_thr = mk(0.0f, 0.0f, 0.0f);  // what the ray started in the trip before still needs from registers
