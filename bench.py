@@ -262,6 +262,7 @@ def main():
                            if use_collective else None),
             "partition": "rows interleaved over ranks (chunk = %d pixels)" % chunk if world > 1 else "whole frame",
             "width": W, "height": H, "spp": spp, "seed": args.seed,
+            "build_flags": pkg.build_flags(),  # the -mllvm switches the compiler accepted (path-tracer-rust_amd/Makefile)
             "ray_bounces_per_frame": main_run["bounces"] // max(1, args.steps),
             # Image.hash of the assembled frame (mod.rs:916-926: SipHash-1-3 of the f32 bits): equal across rank counts,
             # backends and gather paths
@@ -303,7 +304,8 @@ def main():
             "launches": launches,
         }
         out["roofline"].update(per_unit)
-        prof = os.path.join(ROOT, "profiles", "r02_%s_traffic.json" % kernel)
+        prof = next((q for q in (os.path.join(ROOT, "profiles", "%s_%s_traffic.json" % (r, kernel)) for r in ("r03", "r02"))
+                     if os.path.exists(q)), "")
         if os.path.exists(prof):
             try:
                 with open(prof) as f:
@@ -313,23 +315,41 @@ def main():
                 out["roofline"]["traffic"] = tr["hbm_bytes_per_ray"] * out["roofline"]["rays_per_launch"]
                 out["roofline"]["traffic_bytes_per_ray"] = tr["hbm_bytes_per_ray"]
                 out["roofline"]["traffic_source"] = tr.get("source")
-                mix = (tr.get("valu") or {}).get("static_mix")
+                valu = tr.get("valu") or {}
+                mix = valu.get("static_mix")
                 if mix:
-                    # The resource that binds: VALU instruction issue.  Ceiling = 1024 SIMDs x clock cycles; a
-                    # wave-instruction costs its class's measured cycles (profiles/r02_valu_issue_costs.json: 2 / 4 / 8,
-                    # additive in real code); dynamic instructions per ray from the PMC pass, class shares from the ISA.
-                    insts = tr["valu"]["insts_per_ray"]
-                    cyc_per_ray = insts / 64.0 * mix["avg_cost"]
+                    # The resource that binds: VALU instruction issue.  Ceiling = 1024 SIMDs x the clock the chip holds in
+                    # this kernel (in-kernel s_memtime / s_memrealtime stamps of a diagnostic build:
+                    # profiles/r03_<kernel>_phase_budget.json; 2.4 GHz if that file is missing); a wave-instruction costs its
+                    # class's measured cycles (profiles/r02_valu_issue_costs.json: 2 / 4 / 8, additive in real code).  The
+                    # instruction count is dynamic (PMC SQ_INSTS_VALU); so is the mix where the profile has it: the
+                    # instructions by SQ_INSTS_VALU_* category, each category priced with the average class cost of its
+                    # instructions in the ISA (the whole-kernel static mix otherwise, which counts cold code like hot).
+                    dyn = valu.get("dynamic_mix")
+                    avg_cost = dyn["avg_cost"] if dyn else mix["avg_cost"]
+                    clock_ghz, clock_src = 2.4, "nominal peak clock"
+                    pb = os.path.join(ROOT, "profiles", "r03_%s_phase_budget.json" % kernel)
+                    if os.path.exists(pb):
+                        with open(pb) as f:
+                            clock_ghz = json.load(f)["in_kernel_clock_ghz"]
+                        clock_src = "in-kernel s_memtime / s_memrealtime, " + os.path.relpath(pb, ROOT)
+                    peak = 256 * 4 * clock_ghz * 1e9
+                    insts = valu["insts_per_ray"]
+                    cyc_per_ray = insts / 64.0 * avg_cost
                     used = cyc_per_ray * out["roofline"]["rays_per_s"]
                     out["valu_roofline"] = {
                         "kernel": kernel, "bound": "valu", "binds": True,
-                        "achieved": used, "peak": VALU_CYCLES_PEAK, "unit": "SIMD-cycles/s", "frac": used / VALU_CYCLES_PEAK,
-                        "valu_insts_per_ray": insts, "avg_cycles_per_wave_inst": mix["avg_cost"],
+                        "achieved": used, "peak": peak, "unit": "SIMD-cycles/s", "frac": used / peak,
+                        "clock_ghz": clock_ghz, "clock_source": clock_src,
+                        "valu_insts_per_ray": insts, "avg_cycles_per_wave_inst": avg_cost,
+                        "mix": "dynamic (SQ_INSTS_VALU_* categories)" if dyn else "static (whole-kernel ISA)",
+                        "dynamic_category_share": dyn["share"] if dyn else None,
                         "class_counts_static": {k: mix[k] for k in ("A", "B", "C")},
                         "class_cycles": {"A": 2, "B": 4, "C": 8},
-                        "valu_busy_frac_pmc": tr["valu"]["busy_frac"],
-                        "note": "peak = 256 CUs x 4 SIMDs x 2.4 GHz; the chip holds about 2.1 GHz under this load, so "
-                                "frac ~ 0.86 is a saturated VALU (PMC busy fraction beside it)"}
+                        "issue_slots_frac_pmc": valu.get("issue_slots_frac", valu.get("busy_frac")),
+                        "note": "frac = share of the SIMDs' cycles spent issuing VALU instructions, <= 1 by construction of "
+                                "the model; issue_slots_frac_pmc = SQ_ACTIVE_INST_VALU per SIMD-quad-cycle, which ticks once "
+                                "per instruction whatever its class and so exceeds frac by 4 / avg_cycles_per_wave_inst"}
             except Exception:
                 pass
     if rank == 0 and world == 1 and not args.no_variants:

@@ -66,6 +66,7 @@ def lib():
                           % (LIB_PATH, _HERE))
     L = C.CDLL(LIB_PATH)
     L.pt_version.restype = C.c_char_p
+    L.pt_build_flags.restype = C.c_char_p
     L.pt_last_error.restype = C.c_char_p
     L.pt_device_count.restype = C.c_int
     L.pt_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
@@ -217,6 +218,11 @@ class Comm:
             self.close()
         except Exception:
             pass
+
+
+def build_flags():
+    """The back-end (-mllvm) switches the library was built with (the Makefile drops the ones the compiler rejects)."""
+    return lib().pt_build_flags().decode()
 
 
 def image_hash(frame):

@@ -1697,6 +1697,7 @@ __device__ __forceinline__ void shade_surface(const Params &F, const PathRay &in
 // PROBE: the kernel instance pt_ctx_radiance launches - every primary ray is FrameParams' fixed ray at depth depth0.  A
 // template parameter, not a branch on F.probe: the branch alone cost the frame kernels 1.3 % (registers around the two ray
 // makers; A/B on one GPU), and a frame never probes.
+__device__ __forceinline__ PathRay primary_ray_at(const FrameParams &F, uint32_t pix, uint32_t x, uint32_t y, uint32_t s);
 template <bool PROBE = false>
 __device__ __forceinline__ PathRay primary_ray(const FrameParams &F, uint32_t pix, uint32_t s) {
     if (PROBE) {  // pt_ctx_radiance's fixed ray, sample s of "pixel" pix
@@ -1708,8 +1709,11 @@ __device__ __forceinline__ PathRay primary_ray(const FrameParams &F, uint32_t pi
         r.meta = pack_meta(s, F.depth0, 1u);
         return r;
     }
-    const uint32_t y = F.height - 1u - pix / F.width;
-    const uint32_t x = pix % F.width;
+    return primary_ray_at(F, pix, pix % F.width, F.height - 1u - pix / F.width, s);
+}
+// the same with the pixel's column x and row y (from the bottom: mod.rs:805-806) already known: k_pass_cand keeps them per
+// stream pixel in LDS instead of dividing by the frame width for every primary ray
+__device__ __forceinline__ PathRay primary_ray_at(const FrameParams &F, uint32_t pix, uint32_t x, uint32_t y, uint32_t s) {
     const float ysub = (float)((s / 2u) % 2u);
     const float xsub = (float)(s % 2u);
     const u32x4 rnd = draw_block(((uint64_t)F.seed_hi << 32) | F.seed_lo, pix, s, 0u);

@@ -40,9 +40,9 @@ void set_error(const std::string &m);  // pt_api.hip
 extern __shared__ uint4 dyn_lds[];
 
 constexpr uint32_t kDeferCap = 128;  // k_pass: deferred glass hits per wave (63 left over + 64 new at most)
-// k_pass LDS: [u64 acc: 3*m][4 x u32: tail counters][u32 pixel index: m][pad to 16][float4 deferred hits: waves x 3 x kDeferCap]
+// k_pass LDS: [u64 acc: 3*m][4 x u32: tail counters][u32 pixel index, column, row: 3*m][pad to 16][float4 deferred hits: waves x 3 x kDeferCap]
 __host__ __device__ constexpr size_t pass_lds_defer_offset(uint32_t m) {
-    return ((size_t)3 * m * sizeof(unsigned long long) + 16 + (size_t)m * sizeof(uint32_t) + 15) & ~(size_t)15;
+    return ((size_t)3 * m * sizeof(unsigned long long) + 16 + (size_t)3 * m * sizeof(uint32_t) + 15) & ~(size_t)15;
 }
 
 // k_pass_cand LDS: [accumulators, tails, pixel indices as k_pass][per wave: float4 ray_a [128] | u64 key [128] |
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_intersect_cand(DevScene S, RayQue
         const bool cur_valid = it < n_chunks && i < n;
         const uint32_t pending = ring.count;  // entries of chunk it - 1 still queued (< 64)
         bool ran_batch = false;
-        if (it < n_chunks && it * kBlock + (tid & ~63u) < n) {  // (a wave without a ray of this chunk starts nothing)
+        if (it < n_chunks) {
             vec3 o = mk(0.0f, 0.0f, 0.0f), d = o;
             if (cur_valid) {
                 const float4 a = *reinterpret_cast<const float4 *>(qin.od0 + i * 16u);
@@ -624,8 +624,20 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
 #endif
     for (uint32_t k = tid; k < 3u * m; k += kBlock) lds_acc[k] = 0ull;
     if (tid == 0) s_tail_p[0] = s_tail_p[1] = 0u;
+    // per stream pixel: framebuffer index (the RNG counter), and its column and row from the bottom (render_pixel's x, y,
+    // mod.rs:805-806): two divisions here instead of two per primary ray
     uint32_t *lds_pix = s_tail_p + 4;
-    for (uint32_t j = tid; j < mb; j += kBlock) lds_pix[j] = global_pixel(F, stream_pixel(F.n_streams, b, j));
+    uint32_t *lds_px = lds_pix + m, *lds_py = lds_px + m;
+    for (uint32_t j = tid; j < mb; j += kBlock) {
+        const uint32_t pix = global_pixel(F, stream_pixel(F.n_streams, b, j));
+        lds_pix[j] = pix;
+        lds_px[j] = pix % F.width;
+        lds_py[j] = F.height - 1u - pix / F.width;
+    }
+    // ray g of level 0 is (pixel g % mb of the stream, sample g / mb); a lane's rays are 256 apart, so its (pixel, sample)
+    // advance by (256 % mb, 256 / mb) with a carry - no division per trip
+    const uint32_t step_q = kBlock / mb, step_r = kBlock % mb;
+    uint32_t gen_pj = tid % mb, gen_sj = tid / mb;
     CandLds cand;
     const SurfRec *surf_lds = nullptr;
     uint32_t surf_head = 0u;
@@ -826,11 +838,19 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
                 in.o = in.d = in.thr = mk(0.0f, 0.0f, 0.0f);
                 if (cur_valid) {
                     if (depth == 0u) {  // render_pixel's ray for (pixel i % mb of the stream, sample s0 + i / mb)
-                        const uint32_t pj = i % mb, sj = i / mb;
-                        in = primary_ray<PROBE>(F, lds_pix[pj], s0 + sj);
+                        const uint32_t pj = gen_pj, sj = gen_sj;
+                        in = PROBE ? primary_ray<PROBE>(F, lds_pix[pj], s0 + sj) : primary_ray_at(F, lds_pix[pj], lds_px[pj], lds_py[pj], s0 + sj);
                         word = pack_word(pj, sj, PROBE ? F.depth0 : 0u, 1u);
                     } else {
                         load_ray_slice(qin, i, in.o, in.d, in.thr, word);
+                    }
+                }
+                if (depth == 0u) {  // the lane's next ray of level 0
+                    gen_pj += step_r;
+                    gen_sj += step_q;
+                    if (gen_pj >= mb) {
+                        gen_pj -= mb;
+                        gen_sj += 1u;
                     }
                 }
                 cur_thr = in.thr;

@@ -33,6 +33,50 @@ def classify(op, operands):
     return "B"
 
 
+def category(op):
+    """The SQ_INSTS_VALU_* counter an opcode is tallied under (gfx950 PMC: ADD_F32 / MUL_F32 / FMA_F32 / TRANS_F32 / ADD|MUL|FMA_F64
+    / INT32 / INT64 / CVT), or "other" (selects, compares, min/max, moves, lane ops: INSTS_VALU minus the categories)."""
+    base = re.sub(r"_(e32|e64|sdwa|dpp)$", "", op)
+    if base in C_OPS:
+        return "trans_f32"
+    if base.endswith("_f64"):
+        return "f64"
+    if base.startswith("v_cvt"):
+        return "cvt"
+    if base in ("v_add_f32", "v_sub_f32", "v_subrev_f32", "v_pk_add_f32"):
+        return "add_f32"
+    if base in ("v_mul_f32", "v_pk_mul_f32", "v_mul_legacy_f32"):
+        return "mul_f32"
+    if base in ("v_fma_f32", "v_fmac_f32", "v_pk_fma_f32", "v_mad_f32", "v_mac_f32"):
+        return "fma_f32"
+    if base.endswith("_b64") or base.endswith("_u64") or base.endswith("_i64") or base == "v_mad_u64_u32":
+        return "int64"
+    if re.search(r"_(u32|i32|b32|u16|i16|u24|i24)(_|$)", base) and not base.startswith(("v_cmp", "v_cndmask", "v_mov", "v_readlane",
+                                                                                       "v_writelane", "v_readfirstlane", "v_mbcnt")):
+        return "int32"
+    return "other"
+
+
+def mix_by_category(path, name):
+    """Static instruction counts and additive issue cost of the kernel's VALU instructions per PMC category."""
+    in_kernel = False
+    cats = {}
+    for line in open(path):
+        line = line.split(";")[0].rstrip()
+        if not in_kernel:
+            if re.match(r"^[\w.$]+:", line) and name in line and not line.startswith(".L"):
+                in_kernel = True
+            continue
+        if line.strip().startswith("s_endpgm"):
+            break
+        m = re.match(r"^\s+([a-z_0-9]+)\s*(.*)$", line)
+        if m and m.group(1).startswith("v_"):
+            c = cats.setdefault(category(m.group(1)), {"count": 0, "cycles": 0})
+            c["count"] += 1
+            c["cycles"] += {"A": 2, "B": 4, "C": 8}[classify(m.group(1), m.group(2))]
+    return {k: dict(v, avg_cost=v["cycles"] / v["count"]) for k, v in cats.items()} if in_kernel else None
+
+
 def mix(path, name):
     """Static class counts of the first kernel of `path` whose symbol contains `name`: {"A":…, "B":…, "C":…, "valu":…,
     "avg_cost": additive cycles per VALU instruction} - or None when the kernel is not in the listing."""

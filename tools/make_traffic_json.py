@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turn the three PMC passes of tools/pmc_run.sh <tag> into profiles/<tag>_pmc_<what>.json and, per dominant kernel,
-profiles/r02_<kernel>_traffic.json (read by bench.py for roofline.traffic and for the VALU issue figure):
+profiles/r03_<kernel>_traffic.json (read by bench.py for roofline.traffic and for the VALU issue figure):
   hbm_bytes_per_ray   (2 x FETCH_SIZE + WRITE_SIZE) / rays - the gfx950 correction of MI355X_MICROARCH.md's HBM section
   valu                dynamic VALU wave-instructions per ray x 64 (SQ_INSTS_VALU), VALU busy (SQ_ACTIVE_INST_VALU /
                       SQ_BUSY_CYCLES / 8), and the kernel's static issue-class mix (tools/isa_mix.py over
@@ -16,7 +16,8 @@ import isa_mix
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, what, bench_args = sys.argv[1], sys.argv[2], sys.argv[3]
-out = {k: summarise(os.path.join(ROOT, "gpurun_out", "pmc_%s_%s" % (tag, k))) for k in ("sq", "fetch", "write")}
+out = {k: summarise(os.path.join(ROOT, "gpurun_out", "pmc_%s_%s" % (tag, k))) for k in ("sq", "fetch", "write", "mix", "mix2")
+       if os.path.isdir(os.path.join(ROOT, "gpurun_out", "pmc_%s_%s" % (tag, k)))}
 line = [l for l in open(os.path.join(ROOT, "gpurun_out", "pmc_%s_sq.log" % tag)) if l.startswith("{")][-1]
 rays = json.loads(line)["config"]["ray_bounces_per_frame"]
 name = "%s_pmc_%s.json" % (tag, what)
@@ -28,7 +29,11 @@ def kernel(d, frag):
     return next((v for k, v in d.items() if frag in k), None)
 
 
-NOTE = ("insts_per_ray = SQ_INSTS_VALU x 64 / rays (dynamic); busy_frac = SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES / 8; "
+NOTE = ("insts_per_ray = SQ_INSTS_VALU x 64 / rays (dynamic); issue_slots_frac = SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES / 8: the "
+        "counter ticks one quad-cycle per VALU instruction whatever its class (it equals SQ_INSTS_VALU within 2 %), so it is the "
+        "share of 4-cycle issue SLOTS taken, not of time, and reads above 1 for a mix cheaper than 4 cycles; "
+        "dynamic_mix = the instructions by SQ_INSTS_VALU_* category (a PMC pass of its own), each category priced with the "
+        "average class cost of that category's instructions in the ISA: avg_cost is the dynamic counterpart of static_mix's; "
         "static_mix = instruction classes of the kernel's ISA (A: 2 cycles per wave-instruction per SIMD, B: 4, C: 8 - "
         "measured, profiles/r02_valu_issue_costs.json; the classes add up in real code: tools/valu_issue_bench.hip "
         "and the no-packed-instruction A/B of DESIGN section 4); avg_cost = sum(count x cost) / count")
@@ -36,9 +41,10 @@ ASM = os.path.join(ROOT, "path-tracer-rust_amd", "pt_kernels.s")
 # kernel name in the profile -> symbol fragment in the listing (most specific first)
 # (k_pass_cand<STAGED, DEFER, BVH>: "true, true, false" is the bench scene's, "true, false, true" mesh.json's: pt_ctx_pass_kernel
 # calls the latter k_pass_cand_bvh, and bench.py looks its traffic up under that name)
-KERNELS = [("k_pass_cand<true, false, true>", "k_pass_candILb1ELb0ELb1", "k_pass_cand_bvh"),
-           ("k_pass_cand<true, true, false>", "k_pass_candILb1ELb1ELb0", "k_pass_cand"), ("k_pass_bvh", "k_pass_bvhE", None),
-           ("k_pass<", "k_passILb1", None), ("k_intersect", "k_intersectILb0", None), ("k_mega", "k_megaILb0", None)]
+KERNELS = [("k_pass_cand<true, false, true, false>", "k_pass_candILb1ELb0ELb1ELb0", "k_pass_cand_bvh"),
+           ("k_pass_cand<true, true, false, false>", "k_pass_candILb1ELb1ELb0ELb0", "k_pass_cand"), ("k_pass_bvh", "k_pass_bvhILb0", None),
+           ("k_pass<", "k_passILb1ELb0", None), ("k_intersect_cand", "k_intersect_candILb1", None),
+           ("k_intersect<", "k_intersectILb0", "k_intersect"), ("k_mega", "k_megaILb0ELb0", None)]
 done = {}
 for kname, sym, label in KERNELS:
     sq = kernel(out["sq"], kname)
@@ -48,6 +54,24 @@ for kname, sym, label in KERNELS:
     write = kernel(out["write"], kname)["WRITE_SIZE"] * 1024.0
     clean = label or kname.rstrip("<")
     static = isa_mix.mix(ASM, sym) if os.path.exists(ASM) else None
+    dynamic = None
+    mixp = kernel(out.get("mix", {}), kname)
+    if mixp and static:
+        by_cat = isa_mix.mix_by_category(ASM, sym)
+        dyn = {"add_f32": mixp["SQ_INSTS_VALU_ADD_F32"], "mul_f32": mixp["SQ_INSTS_VALU_MUL_F32"], "fma_f32": mixp["SQ_INSTS_VALU_FMA_F32"],
+               "trans_f32": mixp["SQ_INSTS_VALU_TRANS_F32"], "int32": mixp["SQ_INSTS_VALU_INT32"], "int64": mixp["SQ_INSTS_VALU_INT64"],
+               "cvt": mixp["SQ_INSTS_VALU_CVT"]}
+        m2 = kernel(out.get("mix2", {}), kname)
+        if m2:
+            dyn["f64"] = m2["SQ_INSTS_VALU_ADD_F64"] + m2["SQ_INSTS_VALU_MUL_F64"] + m2["SQ_INSTS_VALU_FMA_F64"]
+        dyn["other"] = max(0.0, mixp["SQ_INSTS_VALU"] - sum(dyn.values()))
+        total = sum(dyn.values())
+        cyc = sum(v * (by_cat.get(k, {}).get("avg_cost", static["avg_cost"])) for k, v in dyn.items())
+        dynamic = {"wave_insts": dyn, "share": {k: v / total for k, v in dyn.items()},
+                   "static_avg_cost_by_category": {k: v["avg_cost"] for k, v in by_cat.items()}, "avg_cost": cyc / total}
+        if m2:
+            dynamic["active_lanes"] = m2["SQ_THREAD_CYCLES_VALU"] / max(1.0, sq["SQ_ACTIVE_INST_VALU"])
+            dynamic["wave_cycles_waiting_frac"] = m2["SQ_WAIT_ANY"] / m2["SQ_WAVE_CYCLES"]
     tr = {
         "kernel": clean,
         "rays": rays,
@@ -61,12 +85,13 @@ for kname, sym, label in KERNELS:
                   "--steps 1 --warmup 0 --no-cpu-baseline --no-variants %s`" % (name, bench_args),
         "valu": {
             "insts_per_ray": sq["SQ_INSTS_VALU"] * 64.0 / rays,
-            "busy_frac": sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_BUSY_CYCLES"] / 8.0,
+            "issue_slots_frac": sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_BUSY_CYCLES"] / 8.0,
             "static_mix": static,
+            "dynamic_mix": dynamic,
             "note": NOTE,
         },
     }
     done[clean] = tr
-    with open(os.path.join(ROOT, "profiles", "r02_%s_traffic.json" % clean), "w") as f:
+    with open(os.path.join(ROOT, "profiles", "r03_%s_traffic.json" % clean), "w") as f:
         json.dump(tr, f, indent=1)
 print(json.dumps(done, indent=1))

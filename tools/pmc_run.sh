@@ -9,4 +9,7 @@ ARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-variants $@"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${TAG}_sq -- python3 $R/bench.py $ARGS > $R/gpurun_out/pmc_${TAG}_sq.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${TAG}_fetch -- python3 $R/bench.py $ARGS > $R/gpurun_out/pmc_${TAG}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${TAG}_write -- python3 $R/bench.py $ARGS > $R/gpurun_out/pmc_${TAG}_write.log 2>&1
+# dynamic instruction mix: the VALU instructions by the categories the SQ tallies (tools/make_traffic_json.py prices them)
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${TAG}_mix -- python3 $R/bench.py $ARGS > $R/gpurun_out/pmc_${TAG}_mix.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${TAG}_mix2 -- python3 $R/bench.py $ARGS > $R/gpurun_out/pmc_${TAG}_mix2.log 2>&1
 echo done

@@ -1,11 +1,19 @@
 #!/bin/bash
-# The profile set of a round, on the GPU box: usage tools/profile_round.sh <round tag, e.g. r02>
-#   PMC (three separate passes each: SQ counters, FETCH_SIZE, WRITE_SIZE) for the bench scene, mesh.json and the megakernel,
-#   rocprofv3 --kernel-trace --stats of the default bench command and of the mesh bench command.
-# Everything lands in gpurun_out/; tools/make_traffic_json.py and a copy of the *_kernel_stats.csv go to profiles/.
+# The profile set of a round, on the GPU box: usage tools/profile_round.sh <round tag, e.g. r03>
+#   PMC (separate passes: SQ counters, FETCH_SIZE, WRITE_SIZE, the SQ_INSTS_VALU_* categories) for the bench scene, mesh.json
+#   and the megakernel; rocprofv3 --kernel-trace --stats of the default bench command and of the mesh bench command; the
+#   in-kernel phase budgets of a -DPT_PHASE_STATS build (scratch/libptrace_phase.so: `make -C path-tracer-rust_amd phase`);
+#   the exhaustive sqrt / reciprocal search (tools/rounding_search).
+# Everything lands in gpurun_out/; tools/make_traffic_json.py and copies of the *_kernel_stats.csv go to profiles/.
 set -e
 T=$1
 R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+if [ -f scratch/libptrace_phase.so ]; then
+  PT_LIB=scratch/libptrace_phase.so python3 tools/phase_budget.py cornell 256 gpurun_out/${T}_k_pass_cand_phase_budget.json > gpurun_out/${T}_phase_cornell.txt 2>&1
+  PT_LIB=scratch/libptrace_phase.so python3 tools/phase_budget.py mesh 128 gpurun_out/${T}_k_pass_cand_bvh_phase_budget.json > gpurun_out/${T}_phase_mesh.txt 2>&1
+fi
+if [ -x tools/rounding_search ]; then ./tools/rounding_search > gpurun_out/${T}_rounding_search.json; fi
 $R/tools/pmc_run.sh ${T}a --spp 128
 $R/tools/pmc_run.sh ${T}m --scene mesh --spp 64
 $R/tools/pmc_run.sh ${T}g --backend megakernel --spp 128
