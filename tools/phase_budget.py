@@ -9,6 +9,38 @@ import json
 import os
 import sys
 
+
+def correct(path, shipped_rate):
+    """Add the stamp-corrected budget to a budget file: the shipped library renders the same frame at `shipped_rate` ray
+    bounces per second, i.e. in fewer wave-cycles per bounce than the stamped build; the difference, divided by the number
+    of stamps, is what one stamp costs a wave, and a phase's corrected cycles are its stamped cycles minus its entries
+    times that.  python tools/phase_budget.py --correct <budget.json> <shipped bounces/s>"""
+    res = json.load(open(path))
+    waves_per_chip = 256 * 4 * 4  # SIMDs x waves per SIMD (k_pass_cand's occupancy)
+    shipped_cyc = waves_per_chip * res["in_kernel_clock_ghz"] * 1e9 / shipped_rate * 64.0  # wave-cycles per 64 bounces
+    stamps = sum(p["entries_per_kbounce"] for p in res["phases"].values()) * 0.064
+    per_stamp = (res["wave_cycles_per_bounce"] - shipped_cyc) / stamps
+    tot = 0.0
+    for p in res["phases"].values():
+        p["corrected_wave_cycles_per_bounce"] = max(0.0, p["wave_cycles_per_bounce"] - per_stamp * p["entries_per_kbounce"] * 0.064)
+        tot += p["corrected_wave_cycles_per_bounce"]
+    for p in res["phases"].values():
+        p["corrected_share"] = p["corrected_wave_cycles_per_bounce"] / tot
+    res["shipped_bounces_per_s"] = shipped_rate
+    res["shipped_wave_cycles_per_bounce"] = shipped_cyc
+    res["stamp_cost_wave_cycles"] = per_stamp
+    res["corrected_total_wave_cycles_per_bounce"] = tot
+    json.dump(res, open(path, "w"), indent=1)
+    print("%s: shipped %.2f G bounces/s = %.0f wave-cycles per 64 bounces; a stamp costs %.0f; corrected sum %.0f" %
+          (path, shipped_rate / 1e9, shipped_cyc, per_stamp, tot))
+    for n, p in sorted(res["phases"].items(), key=lambda kv: -kv[1]["corrected_share"]):
+        print("  %-20s %5.1f %%  (stamped %5.1f %%)  %5.1f lanes" % (n, 100 * p["corrected_share"], 100 * p["share"], p["lanes_at_entry"]))
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "--correct":
+    correct(sys.argv[2], float(sys.argv[3]))
+    sys.exit(0)
+
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import ptlib
 from ptlib import PtConfig, PtStats
