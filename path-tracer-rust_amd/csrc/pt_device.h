@@ -238,10 +238,12 @@ struct PhaseLds {
     unsigned long long cnt[4][kPhCount];      // entries << 32 | lanes at entry
 };
 #define PT_PHASE(id) ::pt::phase_to(id)
+#define PT_PHASE_N(id, n) ::pt::phase_to(id, n)
 // keeps a value's computation in front of the next stamp (an empty asm that reads it)
 #define PT_PHASE_PIN(v) asm volatile("" ::"v"(v))
 #else
 #define PT_PHASE(id) do { } while (0)
+#define PT_PHASE_N(id, n) do { } while (0)
 #define PT_PHASE_PIN(v) do { } while (0)
 #endif
 
@@ -351,7 +353,8 @@ __device__ __forceinline__ uint32_t phase_clock() {
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t));
     return (uint32_t)t;
 }
-__device__ __forceinline__ void phase_to(uint32_t id) {
+// `units`: what the phase's "lanes" column counts when that is not the active lanes (a batch's entries); ~0u = the lanes
+__device__ __forceinline__ void phase_to(uint32_t id, uint32_t units = ~0u) {
     PhaseLds &P = phase_lds();
     const uint32_t w = threadIdx.x >> 6;
     const uint64_t m = __builtin_amdgcn_ballot_w64(true);
@@ -359,7 +362,7 @@ __device__ __forceinline__ void phase_to(uint32_t id) {
     if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m)) {
         const unsigned long long st = *(volatile unsigned long long *)&P.state[w];
         atomicAdd(&P.cyc[w][(uint32_t)(st >> 32)], (unsigned long long)(now - (uint32_t)st));
-        atomicAdd(&P.cnt[w][id], (1ull << 32) | (unsigned long long)__builtin_popcountll(m));
+        atomicAdd(&P.cnt[w][id], (1ull << 32) | (unsigned long long)(units != ~0u ? units : (uint32_t)__builtin_popcountll(m)));
         *(volatile unsigned long long *)&P.state[w] = ((unsigned long long)id << 32) | now;
     }
 }
@@ -1296,7 +1299,7 @@ __device__ __forceinline__ unsigned long long cand_spheres(const DevScene &S, ve
 // from its slot in LDS (k_pass_cand keeps the rays of the two chunks in flight there).
 template <bool STAGED>
 __device__ __forceinline__ void cand_batch(const DevScene &S, const CandLds &L, CandRing &R, uint32_t lane, uint32_t count) {
-    PT_PHASE(kPhBatch);
+    PT_PHASE_N(kPhBatch, count);  // (the budget's "lanes" of this phase: entries in the batch)
     const bool valid = lane < count;
     const uint32_t at = (R.head + lane) & (kCandQueueCap - 1u);
     R.head = (R.head + count) & (kCandQueueCap - 1u);
