@@ -122,7 +122,9 @@ struct alignas(16) FlatPairRec {
     float tpad[2];        // slack on the distance along the ray
     uint32_t pair[2];     // TriPairRec index
     uint32_t axis;        // the same for both halves
-    uint32_t pad0;
+    uint32_t sign_exact;  // 1: the SIGN of the distance Triangle::intersect computes for these triangles is that of
+                          // (plane - origin) * direction along the axis, exactly (see filter_flat; pt_host.cpp checks the
+                          // condition) - the filter then drops every ray that does not move towards the plane
 };
 constexpr uint32_t kNoPair = 0xffffffffu;
 #ifndef PT_GRAZING_INV
@@ -1246,18 +1248,45 @@ struct CandRing {
 // The verdicts are WAVE MASKS, not per-lane booleans: every compare lands in an SGPR pair anyway, and combining the pairs
 // with scalar ands / ors keeps the VALU out of it - a ballot of a boolean that is itself a combination of compares costs a
 // v_cndmask and a v_cmp to get back to the mask the compares already were (16 issue cycles per record).
+// THE LOWER END OF THE DISTANCE TEST.  A ray that leaves a wall starts ON that wall's plane - the reference's triangles have no
+// self-intersection epsilon, so Triangle::intersect is evaluated against the wall the ray came from, and its `distance <= 0`
+// (mod.rs:592) decides by rounding.  With the slack a conservative filter needs on distances (`t >= -tpad`) that wall is a
+// candidate of EVERY such ray: 0.8 of the 2.0 candidate records per ray on cornell.  But for triangles in a plane
+// perpendicular to axis a (e1_a = e2_a = 0) the sign of the computed distance is known without computing it:
+//   distance = ((0 + e2_b * (-(e1_c * t_a))) + e2_c * (t_a * e1_b)) * (1 / det),  t_a = o_a - A_a              (mod.rs:577-589)
+//   det      =  (0 + e1_b * (-(e2_c * d_a))) + e1_c * (d_a * e2_b)                                               (mod.rs:563-564)
+// - every term carries t_a (or d_a) as a factor, rounding keeps the sign of a product and of a sum whose terms do not nearly
+// cancel (pt_host.cpp: |e1_b e2_c - e1_c e2_b| >= 0.001 (|e1_b e2_c| + |e1_c e2_b|) for both triangles), so
+// sign(distance) = sign(A_a - o_a) * sign(d_a), and t_a = 0 gives distance = +-0: `distance <= 0` rejects exactly the rays
+// with (A_a - o_a) * sign(d_a) <= 0 (an underflow to zero only rejects more).  For such records the filter keeps a ray only
+// if (plane - origin) * sign(d_a) > 0: about two thirds of the self-candidates go (the origin is on the inner side of the plane,
+// or exactly on it).
 template <int AXIS>
-__device__ __forceinline__ void filter_flat(const FlatPairRec &f, vec3 o, vec3 d, vec3 inv, float bound, uint64_t valid_m,
+__device__ __forceinline__ void filter_flat(const FlatPairRec &f, vec3 o, vec3 d, vec3 inv, vec3 sgn, float bound, uint64_t valid_m,
                                             uint64_t graze, uint64_t *m0, uint64_t *m1) {
     const float oa = AXIS == 0 ? o.x : (AXIS == 1 ? o.y : o.z), ob = AXIS == 0 ? o.y : (AXIS == 1 ? o.z : o.x),
                 oc = AXIS == 0 ? o.z : (AXIS == 1 ? o.x : o.y);
     const float db = AXIS == 0 ? d.y : (AXIS == 1 ? d.z : d.x), dc = AXIS == 0 ? d.z : (AXIS == 1 ? d.x : d.y);
     const float ia = AXIS == 0 ? inv.x : (AXIS == 1 ? inv.y : inv.z);
-    const f32x2 t2 = (ld2(f.pc) - splat2(oa)) * splat2(ia);  // distance to the plane (approximate reciprocal)
+    const float sa = AXIS == 0 ? sgn.x : (AXIS == 1 ? sgn.y : sgn.z);  // +-1 with the sign of d_a
+    const f32x2 tv = ld2(f.pc) - splat2(oa);  // -(tvec_a) of mod.rs:577: exact sign, zero iff the origin is on the plane
+    const f32x2 t2 = tv * splat2(ia);         // distance to the plane (approximate reciprocal)
     const f32x2 yb = __builtin_elementwise_fma(splat2(db), t2, splat2(ob)) - ld2(f.cb);
     const f32x2 zc = __builtin_elementwise_fma(splat2(dc), t2, splat2(oc)) - ld2(f.cc);
     const f32x2 lim = splat2(bound) + ld2(f.tpad);
     uint64_t in[2];
+    if (f.sign_exact) {  // wave-uniform
+        const f32x2 ts = tv * splat2(sa);  // > 0: the ray moves towards the plane (exact: a product with +-1)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+            in[hf] = __builtin_amdgcn_ballot_w64(f_abs(yb[hf]) <= f.hb[hf]) & __builtin_amdgcn_ballot_w64(f_abs(zc[hf]) <= f.hc[hf]) &
+                     __builtin_amdgcn_ballot_w64(t2[hf] <= lim[hf]);
+        // the sign test also holds for grazing rays (it does not use the reciprocal): it is applied to them too
+        const uint64_t fwd0 = __builtin_amdgcn_ballot_w64(ts[0] > 0.0f), fwd1 = __builtin_amdgcn_ballot_w64(ts[1] > 0.0f);
+        *m0 = f.pair[0] != kNoPair ? ((graze | in[0]) & fwd0 & valid_m) : 0ull;
+        *m1 = f.pair[1] != kNoPair ? ((graze | in[1]) & fwd1 & valid_m) : 0ull;
+        return;
+    }
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
         in[hf] = __builtin_amdgcn_ballot_w64(f_abs(yb[hf]) <= f.hb[hf]) & __builtin_amdgcn_ballot_w64(f_abs(zc[hf]) <= f.hc[hf]) &
@@ -1383,15 +1412,16 @@ __device__ __forceinline__ void cand_filter_and_drain(const DevScene &S, const C
     // rays that graze the planes of an axis (|d_a| < kGrazing, or NaN): not judged by the filters of that axis
     const uint64_t gz_x = __builtin_amdgcn_ballot_w64(!(f_abs(d.x) >= kGrazing)), gz_y = __builtin_amdgcn_ballot_w64(!(f_abs(d.y) >= kGrazing)),
                    gz_z = __builtin_amdgcn_ballot_w64(!(f_abs(d.z) >= kGrazing));
+    const vec3 sgn = mk(__builtin_copysignf(1.0f, d.x), __builtin_copysignf(1.0f, d.y), __builtin_copysignf(1.0f, d.z));
     for (uint32_t p = 0; p < S.n_flat_pairs; ++p) {
         const FlatPairRec f = ld_uniform(S.flat_pairs + p);
         uint64_t m0, m1;
         if (f.axis == 0u)
-            filter_flat<0>(f, o, d, inv, bound, valid_m, gz_x, &m0, &m1);
+            filter_flat<0>(f, o, d, inv, sgn, bound, valid_m, gz_x, &m0, &m1);
         else if (f.axis == 1u)
-            filter_flat<1>(f, o, d, inv, bound, valid_m, gz_y, &m0, &m1);
+            filter_flat<1>(f, o, d, inv, sgn, bound, valid_m, gz_y, &m0, &m1);
         else
-            filter_flat<2>(f, o, d, inv, bound, valid_m, gz_z, &m0, &m1);
+            filter_flat<2>(f, o, d, inv, sgn, bound, valid_m, gz_z, &m0, &m1);
         push2(m0, f.pair[0], m1, f.pair[1]);
         drain();
     }

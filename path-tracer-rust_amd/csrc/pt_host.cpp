@@ -578,6 +578,7 @@ bool flatten_scene(const pt_camera &cam, const pt_object *objs, uint32_t n_objs,
                     f.hb[0] = f.hb[1] = f.hc[0] = f.hc[1] = -1.0f;  // empty rectangle: |x - c| <= -1 never holds
                     f.tpad[0] = f.tpad[1] = 0.0f;
                     f.axis = (uint32_t)a;
+                    f.sign_exact = 1u;  // (cleared by the first half that does not qualify; a filler half qualifies)
                     by_axis[a].push_back(f);
                 }
                 FlatPairRec &f = by_axis[a].back();
@@ -588,6 +589,16 @@ bool flatten_scene(const pt_camera &cam, const pt_object *objs, uint32_t n_objs,
                 f.cc[hf] = 0.5f * (lov[c] + hiv[c]);
                 f.hc[hf] = 0.5f * (hiv[c] - lov[c]) + pad + 4.0f * e * (f_abs(lov[c]) + f_abs(hiv[c]));
                 f.tpad[hf] = pad;
+                // filter_flat's sign rule: the two products whose difference is the plane normal's component along the axis
+                // must not nearly cancel, for both triangles of the record, in Triangle::intersect's `distance` numerator and
+                // in its determinant alike (the same two products of edge components, mod.rs:563-564, 583-589)
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    if (tp.id[h2] == kNoTri) continue;
+                    const float e1v[3] = {tp.e1x[h2], tp.e1y[h2], tp.e1z[h2]}, e2v[3] = {tp.e2x[h2], tp.e2y[h2], tp.e2z[h2]};
+                    const double pa = (double)e1v[b] * e2v[c], pb = (double)e1v[c] * e2v[b];
+                    if (!(std::fabs(pa - pb) >= 1e-3 * (std::fabs(pa) + std::fabs(pb))) || !std::isfinite(pa) || !std::isfinite(pb))
+                        f.sign_exact = 0u;
+                }
                 f.pair[hf] = (uint32_t)filtered.size();  // + n_other_pairs below
                 filtered.push_back(cand_rec(i, pp));
                 ++fill[a];
