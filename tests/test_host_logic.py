@@ -213,3 +213,46 @@ def test_build_flags_are_reported():
     L.pt_build_flags.restype = C.c_char_p
     flags = L.pt_build_flags().decode()
     assert all(tok.startswith("-") or tok == "" for tok in flags.split(" ")), flags
+
+
+SIGN_SRC = r"""
+#include <cstdio>
+#include <string>
+#include <vector>
+#include "ptrace.h"
+#include "pt_host.h"
+using namespace pt;
+// argv[1] = 0: two quads in the plane z = 1 made of well-shaped triangles; 1: the same plane, but one triangle whose two edge
+// products nearly cancel (a sliver: e1 = (1, 1), e2 = (1, 1.0005)): the plane normal's component is 0.0005 of the products
+int main(int argc, char **argv) {
+    const bool sliver = argv[1][0] == '1';
+    pt_camera cam = {{0, 0, 5}, {0, 0, -1}, 0.035f, 0.036f, 1.5f};
+    std::vector<pt_triangle> tris;
+    tris.push_back({{0, 0, 1}, {1, 0, 1}, {0, 1, 1}});
+    tris.push_back({{1, 0, 1}, {1, 1, 1}, {0, 1, 1}});
+    if (sliver) tris[1] = {{0, 0, 1}, {1, 1, 1}, {1, 1.0005f, 1}};
+    pt_object o{};
+    o.kind = PT_MESH;
+    o.tri_count = 2;
+    o.bs_radius = 100.0f;
+    host::FlatScene fs;
+    std::string err;
+    if (!host::flatten_scene(cam, &o, 1, tris.data(), 2, fs, err)) { printf("FAIL %s\n", err.c_str()); return 1; }
+    if (fs.flat_pairs.size() != 1) { printf("FAIL flat_pairs %zu\n", fs.flat_pairs.size()); return 1; }
+    printf("OK axis %u sign_exact %u\n", fs.flat_pairs[0].axis, fs.flat_pairs[0].sign_exact);
+    return 0;
+}
+"""
+
+
+def test_flat_filter_sign_rule_needs_well_shaped_triangles(tmp_path):
+    """FlatPairRec.sign_exact (filter_flat drops rays that do not move towards the plane: the sign of Triangle::intersect's
+    distance is then known exactly) is only set when the two edge products whose difference is the plane normal do not
+    nearly cancel; a sliver keeps the conservative distance test.  cornell.json's walls all qualify."""
+    src = tmp_path / "s.cpp"
+    src.write_text(SIGN_SRC)
+    exe = str(tmp_path / "s")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ptlib.PKG, "csrc"), "-I", os.path.join(ptlib.ROOT, "include"),
+                           str(src), "-o", exe, "-L", ptlib.PKG, "-lptrace_hip", "-Wl,-rpath," + ptlib.PKG])
+    assert subprocess.check_output([exe, "0"]).decode().split() == ["OK", "axis", "2", "sign_exact", "1"]
+    assert subprocess.check_output([exe, "1"]).decode().split() == ["OK", "axis", "2", "sign_exact", "0"]
