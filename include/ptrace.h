@@ -228,6 +228,14 @@ int pt_ctx_radiance(pt_ctx *ctx, const float o[3], const float d[3], uint32_t de
 int pt_ctx_intersect(pt_ctx *ctx, const float *o, const float *d, uint32_t n, float *t,
                      int32_t *object_id, int32_t *tri_id, float *x, float *normal);
 
+/* Diagnostics: intersect_scene (mod.rs:631-659) for n rays through the INTERSECT STEP OF THE WAVEFRONT PIPELINE itself - the
+ * rays are laid out as ray streams and run through the kernel PT_FLAG_SEPARATE_KERNELS launches per depth (candidate scan:
+ * conservative filters, per-wave ring, dense exact batches; with PT_FLAG_NO_BVH every triangle per ray; scenes with BVH
+ * meshes: scan + parked walks) - where pt_ctx_intersect above goes through the single-ray query kernel.  t[i] = the hit
+ * distance (+inf on a miss), id[i] = -1 (miss), the object index of a sphere, or n_objs + the flattened triangle index.
+ * For ray-by-ray parity tests of the scan forms (rays that start ON a triangle included). */
+int pt_ctx_intersect_streams(pt_ctx *ctx, const float *o, const float *d, uint32_t n, uint32_t flags, float *t, int32_t *id);
+
 /* SceneObjectData::intersect_bounds (mod.rs:282-290) of object `object` for n rays: a sphere is tested itself
  * (intersect_sphere), a mesh through Triangle::intersect over the 12 triangles of Mesh.bounding_box.  hit[i] = 1/0;
  * t / x / normal as Hit holds them (zero on a miss).  Outputs may be NULL. */

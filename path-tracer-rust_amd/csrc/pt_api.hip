@@ -1192,6 +1192,70 @@ int pt_ctx_radiance(pt_ctx *c, const float o[3], const float d[3], uint32_t dept
     return PT_OK;
 }
 
+int pt_ctx_intersect_streams(pt_ctx *c, const float *o, const float *d, uint32_t n, uint32_t flags, float *t, int32_t *id) {
+    if (!c || !o || !d || !t || !id) {
+        set_error("NULL argument");
+        return PT_ERR_INVALID;
+    }
+    if (!c->has_scene) {
+        set_error("no scene set");
+        return PT_ERR_INVALID;
+    }
+    if (n == 0) return PT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    // the rays as ray streams of 4096 slots (the queue layout of the wavefront pipeline), one workgroup per stream
+    const uint32_t cap = 4096u, K = (n + cap - 1u) / cap;
+    std::vector<float4> h0((size_t)K * cap);
+    std::vector<float2> h1((size_t)K * cap);
+    std::vector<uint32_t> hc(K);
+    for (uint32_t i = 0; i < n; ++i) {
+        h0[i] = make_float4(o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i]);
+        h1[i] = make_float2(d[3 * i + 1], d[3 * i + 2]);
+    }
+    for (uint32_t b = 0; b < K; ++b) hc[b] = (n - b * cap) < cap ? (n - b * cap) : cap;
+    DevBuf<float4> d0;
+    DevBuf<float2> d1, dh;
+    DevBuf<uint32_t> dc;
+    DevBuf<unsigned long long> dr;
+    int rc;
+    if ((rc = d0.ensure(h0.size())) || (rc = d1.ensure(h1.size())) || (rc = dh.ensure(h1.size())) || (rc = dc.ensure(K)) || (rc = dr.ensure(K)))
+        return rc;
+    hipStream_t st = c->stream;
+    hipError_t e = hipMemcpyAsync(d0.p, h0.data(), h0.size() * sizeof(float4), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d1.p, h1.data(), h1.size() * sizeof(float2), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(dc.p, hc.data(), K * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(dr.p, 0, K * sizeof(unsigned long long), st);
+    if (e == hipSuccess) {
+        DevScene S = c->scene;
+        S.n_bvh_nodes = (flags & PT_FLAG_NO_BVH) ? 0u : c->n_bvh_nodes;
+        S.planar = (flags & PT_FLAG_NO_BVH) ? 0u : 1u;
+        S.cand_scan = cand_scan_for(c, flags);
+        RayQueue q;
+        q.od0 = d0.p;
+        q.od1 = d1.p;
+        q.tp = nullptr;
+        launch_intersect(st, K, S, q, dh.p, dc.p, cap, dr.p);
+        e = hipGetLastError();
+    }
+    std::vector<float2> hh(h1.size());
+    if (e == hipSuccess) e = hipMemcpyAsync(hh.data(), dh.p, hh.size() * sizeof(float2), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    d0.release();
+    d1.release();
+    dh.release();
+    dc.release();
+    dr.release();
+    if (e != hipSuccess) {
+        set_error(std::string("pt_ctx_intersect_streams: ") + hipGetErrorString(e));
+        return PT_ERR_HIP;
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        t[i] = hh[i].x;
+        memcpy(&id[i], &hh[i].y, sizeof(int32_t));
+    }
+    return PT_OK;
+}
+
 int pt_ctx_intersect(pt_ctx *c, const float *o, const float *d, uint32_t n, float *t, int32_t *object_id,
                      int32_t *tri_id, float *x, float *normal) {
     if (!c || !o || !d) {

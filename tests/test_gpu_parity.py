@@ -1547,3 +1547,63 @@ def test_out_of_device_memory_halves_the_pass(gpu):
         L.pt_ctx_destroy(ctx)
     assert st1.passes > 2, st1.passes  # 256 Mi rays would have been two passes
     assert st1.ray_bounces == st0.ray_bounces and np.array_equal(got, want)
+
+
+def _oracle_ids(sc, oid, tid):
+    """(object, triangle-in-object) of the oracle -> the hit id of the stream kernels: object index for a sphere, n_objs +
+    flattened triangle index for a triangle, -1 for a miss."""
+    off = np.array([sc.objs[i].tri_offset for i in range(sc.n_objs)], np.int64)
+    ids = np.where(oid < 0, -1, np.where(tid < 0, oid, sc.n_objs + off[np.maximum(oid, 0)] + tid))
+    return ids.astype(np.int32)
+
+
+@pytest.mark.parametrize("sid", ["cornell", "mesh", "cartesian"])
+def test_stream_intersect_kernels_ray_by_ray(gpu, sid):
+    """The intersect step of the wavefront pipeline ITSELF, ray by ray against intersect_scene of the oracle (bit-exact
+    distance, same primitive): the candidate scan (k_intersect_cand: filters, ring, dense exact batches - the scan k_pass_cand
+    runs), the every-triangle scan (PT_FLAG_NO_BVH) and, for mesh.json, scan + parked walks.  Rays: every ray the path
+    tracer casts for a block of pixels - four fifths of them start ON a triangle, where the reference's epsilon-free
+    Triangle::intersect decides a self-hit by rounding and the flat filter's exact sign rule (filter_flat) must agree - and
+    the same rays with their origin moved by -2, -1, +1, +2 ulp along each axis: origins on either side of their wall."""
+    L, ctx = gpu
+    O = ptlib.oracle()
+    sc = ptlib.load_scene_py(ptlib.scene_path(sid))
+    set_scene(gpu, sc)
+    w, h, spp = 48, 32, 2 if sid == "mesh" else 6
+    cfg = PtoConfig(w, h, spp, 0, 23)
+    cap = w * h * spp * 16
+    rays = np.zeros((cap, 6), dtype=np.float32)
+    ps = sc.pto()
+    n = O.pto_dump_rays(C.byref(ps), C.byref(cfg), 0, w * h, _np_f(rays), cap)
+    assert 0 < n < cap
+    o0 = np.ascontiguousarray(rays[:n, :3])
+    d0 = np.ascontiguousarray(rays[:n, 3:])
+    os_, ds_ = [o0], [d0]
+    sub = slice(0, min(n, 6000))
+    for axis in range(3):
+        for k in (-2, -1, 1, 2):
+            o = o0[sub].copy()
+            col = o[:, axis]
+            for _ in range(abs(k)):
+                col = np.nextafter(col, np.float32(np.inf if k > 0 else -np.inf)).astype(np.float32)
+            o[:, axis] = col
+            os_.append(o)
+            ds_.append(d0[sub])
+    o = np.ascontiguousarray(np.concatenate(os_))
+    d = np.ascontiguousarray(np.concatenate(ds_))
+    m = len(o)
+    t0, oid0, tid0, _, _ = ptlib.oracle_intersect(sc, o, d)
+    want_id = _oracle_ids(sc, oid0, tid0)
+    hit = want_id >= 0
+    assert hit.sum() > (0.8 * m if sid != "cartesian" else 0)  # (cartesian.json: a few spheres in empty space)
+    for flags in (0, ptlib.FLAG_NO_BVH):
+        t = np.zeros(m, np.float32)
+        ids = np.zeros(m, np.int32)
+        rc = L.pt_ctx_intersect_streams(ctx, _np_f(o), _np_f(d), m, flags, _np_f(t), ids.ctypes.data_as(ptlib.i32p))
+        assert rc == 0, L.pt_last_error()
+        assert np.array_equal(ids, want_id), (sid, flags, int((ids != want_id).sum()))
+        assert np.array_equal(t[hit].view(np.uint32), t0[hit].view(np.uint32)), (sid, flags)
+        assert np.all(np.isinf(t[~hit]))
+    # the self-hits the reference's arithmetic really produces are in the sample: rays that hit the triangle they start on
+    if sid == "cornell":
+        assert (t0[hit] < 1e-5).sum() > 0
