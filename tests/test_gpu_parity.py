@@ -1197,30 +1197,41 @@ def _pixels_against_oracle(gpu, sc, w, h, spp, seed, pixels, backend=0):
 def test_parity_at_baseline_spp(gpu):
     """The 1e-4 bar at the sample counts BASELINE.json names.  The GPU sums radiance exactly (32.32 fixed point, top
     down), the reference sequentially in f32 (mod.rs:846): the gap grows with spp, so it is measured where it is
-    largest: 300 pixels of cornell 1024x768 at 1024 and at 4096 spp (configs 2, 3), 300 pixels of mesh.json at 1024 spp
-    (config 4) and 50 pixels of cornell 4096x4096 at 16384 spp (config 5), HIP against the oracle's render_pixel."""
+    largest: 300 pixels (12 image rows) of cornell 1024x768 at 1024 and at 4096 spp (configs 2, 3), 300 pixels of mesh.json
+    at 1024 spp and 60 at 4096 spp (config 4) and 50 pixels of cornell 4096x4096 at 16384 spp (config 5, both backends), HIP
+    against the oracle's render_pixel.  The measured maxima are written to gpurun_out/ when that directory exists."""
+    measured = {}
     sc = ptlib.load_scene_py(ptlib.scene_path("cornell"))
     rng = np.random.default_rng(2026)
     w, h = 1024, 768
-    rows = rng.choice(h, size=6, replace=False)
-    pix = np.concatenate([r * w + rng.choice(w, size=50, replace=False) for r in rows])
+    rows = rng.choice(h, size=12, replace=False)
+    pix = np.concatenate([r * w + rng.choice(w, size=25, replace=False) for r in rows])
     for spp in (1024, 4096):
         err = _pixels_against_oracle(gpu, sc, w, h, spp, 1, pix)
-        print("cornell %dx%d @%d spp: max |gpu - oracle| over %d pixels = %.3g" % (w, h, spp, len(pix), err))
+        measured["cornell_%dx%d_%dspp_%dpx" % (w, h, spp, len(pix))] = err
         assert err <= TOL, (spp, err)
     mesh = ptlib.load_scene_py(ptlib.scene_path("mesh"))
     rows = [150, 300, 384, 450, 520, 600]  # (the mesh covers the middle of the frame)
     pix = np.concatenate([r * w + rng.choice(w, size=50, replace=False) for r in rows])
     err = _pixels_against_oracle(gpu, mesh, w, h, 1024, 1, pix)
-    print("mesh %dx%d @1024 spp: max |gpu - oracle| over %d pixels = %.3g" % (w, h, len(pix), err))
+    measured["mesh_%dx%d_1024spp_%dpx" % (w, h, len(pix))] = err
+    assert err <= TOL, err
+    pix = np.concatenate([r * w + rng.choice(w, size=10, replace=False) for r in rows])
+    err = _pixels_against_oracle(gpu, mesh, w, h, 4096, 1, pix)
+    measured["mesh_%dx%d_4096spp_%dpx" % (w, h, len(pix))] = err
     assert err <= TOL, err
     w = h = 4096
     rows = rng.choice(h, size=5, replace=False)
     pix = np.concatenate([r * w + rng.choice(w, size=10, replace=False) for r in rows])
     for backend in (ptlib.BACKEND_WAVEFRONT, ptlib.BACKEND_MEGAKERNEL):
         err = _pixels_against_oracle(gpu, sc, w, h, 16384, 1, pix, backend)
-        print("cornell %dx%d @16384 spp backend %d: max |gpu - oracle| over %d pixels = %.3g" % (w, h, backend, len(pix), err))
+        measured["cornell_%dx%d_16384spp_%dpx_backend%d" % (w, h, len(pix), backend)] = err
         assert err <= TOL, (backend, err)
+    out_dir = os.path.join(ptlib.ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        import json
+        with open(os.path.join(out_dir, "parity_at_baseline_spp.json"), "w") as f:
+            json.dump({"max_abs_diff_vs_oracle": measured, "tolerance": TOL}, f, indent=1)
 
 
 def _comm_gather_world_1(L, ctx):
@@ -1607,3 +1618,24 @@ def test_stream_intersect_kernels_ray_by_ray(gpu, sid):
     # the self-hits the reference's arithmetic really produces are in the sample: rays that hit the triangle they start on
     if sid == "cornell":
         assert (t0[hit] < 1e-5).sum() > 0
+
+
+def test_progress_at_part_boundaries(gpu):
+    """A call rendered in parts (more than 1.5 M pixels) whose parts take one pass each makes no callback from inside a
+    part (those start at the third pass); the part boundaries are progress points of their own: 1/3, 2/3, then 1.0."""
+    L, ctx = gpu
+    sc = ptlib.load_scene_py(ptlib.scene_path("cornell"))
+    set_scene(gpu, sc)
+    w, h = 2048, 1040  # parts of 1 048 576 + 1 048 576 + 32 768 pixels
+    d_out = C.c_void_p()
+    assert L.pt_device_malloc(0, w * h * 12, C.byref(d_out)) == 0
+    seen = []
+    cb = ptlib.PROGRESS_FN(lambda user, frac: seen.append(frac))
+    cfg = PtConfig(w, h, 1, 0, 3, 0, 0, 0, 0)
+    cfg.progress_ms = ptlib.PROGRESS_EVERY_PASS
+    st = PtStats()
+    rc = L.pt_ctx_render(ctx, C.byref(cfg), d_out, None, None, C.cast(cb, C.c_void_p), None, C.byref(st))
+    assert rc == 0, L.pt_last_error()
+    assert st.passes == 3
+    assert len(seen) == 3 and abs(seen[0] - 1 / 3) < 1e-6 and abs(seen[1] - 2 / 3) < 1e-6 and seen[2] == 1.0, seen
+    assert L.pt_device_free(0, d_out) == 0
