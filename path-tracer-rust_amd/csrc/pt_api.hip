@@ -135,8 +135,8 @@ struct pt_ctx {
     DevBuf<int32_t> q_oid, q_tid;
     // wavefront queues
     uint32_t K = 0, cap = 0;
-    DevBuf<float4> q_od0[2], q_tp[2];
-    DevBuf<float2> q_od1[2], hit;
+    DevBuf<char> q_buf[2];  // the two ray-queue containers: K slices of cap * 40 bytes each (RayQueue, pt_kernels.h)
+    DevBuf<float2> hit;
     DevBuf<uint32_t> cnt, flags;
     DevBuf<unsigned long long> blk_rays, acc, total_rays;
     std::vector<hipEvent_t> ev_pool;
@@ -251,9 +251,7 @@ FrameParams make_frame(const pt_ctx *ctx, const pt_config *cfg, uint32_t idx_beg
 
 RayQueue queue_of(pt_ctx *c, int which) {
     RayQueue q;
-    q.od0 = c->q_od0[which].p;
-    q.od1 = c->q_od1[which].p;
-    q.tp = c->q_tp[which].p;
+    q.buf = c->q_buf[which].p;
     return q;
 }
 
@@ -298,7 +296,7 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
     if (!want) {
         want = 96u << 20;
         size_t held = c->hit.bytes();
-        for (int w = 0; w < 2; ++w) held += c->q_od0[w].bytes() + c->q_od1[w].bytes() + c->q_tp[w].bytes();
+        for (int w = 0; w < 2; ++w) held += c->q_buf[w].bytes();
         size_t avail = c->mem_budget;
         if (!avail) {
             size_t mem_free = 0, mem_total = 0;
@@ -354,7 +352,8 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
         K = (uint32_t)((npix + m - 1) / m);
         // a primary ray has at most 4 descendants alive at one depth (two refract splits, mod.rs:760)
         const uint64_t cap64 = (4ull * m * spp_pass + kBlock - 1) / kBlock * kBlock;
-        if (cap64 * K > 0xffffffffull / 2) {
+        // (slot indices are 32-bit over the whole queue, byte offsets 32-bit inside a stream's slice of cap * 40 bytes)
+        if (cap64 * K > 0xffffffffull / 2 || cap64 * kRayBytes > 0xffffffffull) {
             if (spp_pass > 1u && !cfg->rays_per_pass) {  // (a default this large only on a device with > 680 GB)
                 want /= 2;
                 continue;
@@ -365,8 +364,7 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
         cap = (uint32_t)cap64;
         const size_t slots = (size_t)K * cap;
         int rc = PT_OK;
-        for (int w = 0; w < 2 && !rc; ++w)
-            if ((rc = c->q_od0[w].ensure(slots, true)) || (rc = c->q_od1[w].ensure(slots, true)) || (rc = c->q_tp[w].ensure(slots, true))) break;
+        for (int w = 0; w < 2 && !rc; ++w) rc = c->q_buf[w].ensure(queue_bytes(K, cap), true);
         // scenes without BVH meshes run a pass as one launch (k_pass), BVH scenes as k_pass_bvh unless their nodes are staged
         // in LDS; PT_FLAG_SEPARATE_KERNELS / PT_PASS_KERNEL=0 / PT_PASS_BVH=0 keep the three-kernel form (A/B, profiling).
         // Only that form needs the hit records: k_pass keeps hits in registers.
@@ -378,11 +376,7 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
         if (!rc) break;
         if (rc != PT_ERR_NOMEM_INTERNAL) return rc;
         // out of device memory: give back what this attempt took and try passes of half the size
-        for (int w = 0; w < 2; ++w) {
-            c->q_od0[w].release();
-            c->q_od1[w].release();
-            c->q_tp[w].release();
-        }
+        for (int w = 0; w < 2; ++w) c->q_buf[w].release();
         c->hit.release();
         if (spp_pass <= 1u) return PT_ERR_HIP;  // (the message names the allocation that failed)
         want = (uint64_t)npix * (spp_pass / 2u ? spp_pass / 2u : 1u);
@@ -716,11 +710,7 @@ void pt_ctx_destroy(pt_ctx *c) {
     c->q_n.release();
     c->q_oid.release();
     c->q_tid.release();
-    for (int w = 0; w < 2; ++w) {
-        c->q_od0[w].release();
-        c->q_od1[w].release();
-        c->q_tp[w].release();
-    }
+    for (int w = 0; w < 2; ++w) c->q_buf[w].release();
     c->hit.release();
     c->cnt.release();
     c->flags.release();
@@ -1205,24 +1195,25 @@ int pt_ctx_intersect_streams(pt_ctx *c, const float *o, const float *d, uint32_t
     HIP_TRY(hipSetDevice(c->device));
     // the rays as ray streams of 4096 slots (the queue layout of the wavefront pipeline), one workgroup per stream
     const uint32_t cap = 4096u, K = (n + cap - 1u) / cap;
-    std::vector<float4> h0((size_t)K * cap);
-    std::vector<float2> h1((size_t)K * cap);
+    std::vector<char> hq(queue_bytes(K, cap), 0);  // slice b: [od0: cap x 16][tp: cap x 16][od1: cap x 8]
     std::vector<uint32_t> hc(K);
     for (uint32_t i = 0; i < n; ++i) {
-        h0[i] = make_float4(o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i]);
-        h1[i] = make_float2(d[3 * i + 1], d[3 * i + 2]);
+        char *slice = hq.data() + (size_t)(i / cap) * cap * kRayBytes;
+        const uint32_t j = i % cap;
+        const float4 a = make_float4(o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i]);
+        const float2 bq = make_float2(d[3 * i + 1], d[3 * i + 2]);
+        memcpy(slice + (size_t)j * 16u, &a, sizeof a);
+        memcpy(slice + (size_t)cap * 32u + (size_t)j * 8u, &bq, sizeof bq);
     }
     for (uint32_t b = 0; b < K; ++b) hc[b] = (n - b * cap) < cap ? (n - b * cap) : cap;
-    DevBuf<float4> d0;
-    DevBuf<float2> d1, dh;
+    DevBuf<char> d0;
+    DevBuf<float2> dh;
     DevBuf<uint32_t> dc;
     DevBuf<unsigned long long> dr;
     int rc;
-    if ((rc = d0.ensure(h0.size())) || (rc = d1.ensure(h1.size())) || (rc = dh.ensure(h1.size())) || (rc = dc.ensure(K)) || (rc = dr.ensure(K)))
-        return rc;
+    if ((rc = d0.ensure(hq.size())) || (rc = dh.ensure((size_t)K * cap)) || (rc = dc.ensure(K)) || (rc = dr.ensure(K))) return rc;
     hipStream_t st = c->stream;
-    hipError_t e = hipMemcpyAsync(d0.p, h0.data(), h0.size() * sizeof(float4), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(d1.p, h1.data(), h1.size() * sizeof(float2), hipMemcpyHostToDevice, st);
+    hipError_t e = hipMemcpyAsync(d0.p, hq.data(), hq.size(), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(dc.p, hc.data(), K * sizeof(uint32_t), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemsetAsync(dr.p, 0, K * sizeof(unsigned long long), st);
     if (e == hipSuccess) {
@@ -1231,17 +1222,14 @@ int pt_ctx_intersect_streams(pt_ctx *c, const float *o, const float *d, uint32_t
         S.planar = (flags & PT_FLAG_NO_BVH) ? 0u : 1u;
         S.cand_scan = cand_scan_for(c, flags);
         RayQueue q;
-        q.od0 = d0.p;
-        q.od1 = d1.p;
-        q.tp = nullptr;
+        q.buf = d0.p;
         launch_intersect(st, K, S, q, dh.p, dc.p, cap, dr.p);
         e = hipGetLastError();
     }
-    std::vector<float2> hh(h1.size());
+    std::vector<float2> hh((size_t)K * cap);
     if (e == hipSuccess) e = hipMemcpyAsync(hh.data(), dh.p, hh.size() * sizeof(float2), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     d0.release();
-    d1.release();
     dh.release();
     dc.release();
     dr.release();

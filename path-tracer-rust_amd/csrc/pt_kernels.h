@@ -12,12 +12,14 @@ constexpr uint32_t kBlockBvh = 256;  // workgroup of the intersect kernel of sce
 constexpr uint32_t kMaxStreamPixels = 1024;  // pixels owned by one stream (24 KiB of LDS accumulators at most)
 constexpr uint32_t kLevels = 13;    // ray depths 0..11 plus the (always empty) level written by the last shade
 
-// SoA-of-packets ray queue; every array holds K streams of `cap` slots (see pt_kernels.hip)
+// The ray queue: K stream slices of cap * 40 bytes, each slice three arrays of `cap` slots one after the other -
+//   [od0: float4 origin xyz, direction x][tp: float4 throughput rgb, bookkeeping word (pack_word)][od1: float2 direction yz]
+// - so that a workgroup addresses its stream with ONE scalar base and 32-bit byte offsets (see StreamSlice, pt_kernels.hip).
 struct RayQueue {
-    float4 *od0;     // origin xyz, direction x
-    float2 *od1;     // direction yz
-    float4 *tp;      // throughput rgb, bookkeeping word (pack_word: pixel-in-stream | sample-in-pass | depth | branch)
+    char *buf;
 };
+constexpr uint32_t kRayBytes = 40;
+inline size_t queue_bytes(size_t K, uint32_t cap) { return K * (size_t)cap * kRayBytes; }
 
 // one whole pass of a scene without BVH meshes in one launch (see k_pass)
 hipError_t launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const FrameParams &F, const RayQueue &q0,

@@ -61,36 +61,36 @@ __device__ __forceinline__ uint32_t lane_prefix(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-__device__ __forceinline__ void store_ray(const RayQueue &q, size_t at, vec3 o, vec3 d, vec3 thr, uint32_t word) {
-    q.od0[at] = make_float4(o.x, o.y, o.z, d.x);
-    q.od1[at] = make_float2(d.y, d.z);
-    q.tp[at] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(word));
-}
-
-// One stream's slice of a queue, addressed by 32-bit byte offsets from scalar base pointers (slot * 16 / 8 fits 32 bits:
-// cap < 2^27): the loads and stores then take the base from an SGPR pair and one VGPR offset instead of a 64-bit
-// address computed per lane.
+// One stream's slice of a queue: ONE scalar base pointer and two 32-bit offsets (the starts of the throughput and the
+// direction-yz arrays inside the slice).  Every access is base (an SGPR pair) + a 32-bit VGPR byte offset - `slot * 16 +
+// off_tp` is one v_lshl_add with the offset as its scalar operand.  (Rounds 1-2 kept three arrays per queue and three 64-bit
+// slice bases per level and direction: twelve SGPRs that the pass kernels, short of scalar registers, parked in VGPR lanes
+// and fetched back with two v_readlane per access.)
 struct StreamSlice {
-    char *od0, *od1, *tp;
+    char *base;
+    uint32_t off_tp, off_od1;
 };
-__device__ __forceinline__ StreamSlice slice_of(const RayQueue &q, size_t base) {
+__device__ __forceinline__ StreamSlice slice_of(const RayQueue &q, uint32_t b, uint32_t cap) {
     StreamSlice s;
-    s.od0 = reinterpret_cast<char *>(q.od0 + base);
-    s.od1 = reinterpret_cast<char *>(q.od1 + base);
-    s.tp = reinterpret_cast<char *>(q.tp + base);
+    s.base = q.buf + (size_t)b * cap * kRayBytes;
+    s.off_tp = cap * 16u;
+    s.off_od1 = cap * 32u;
     return s;
 }
+__device__ __forceinline__ float4 ld_od0(const StreamSlice &q, uint32_t i) { return *reinterpret_cast<const float4 *>(q.base + i * 16u); }
+__device__ __forceinline__ float4 ld_tp(const StreamSlice &q, uint32_t i) { return *reinterpret_cast<const float4 *>(q.base + (i * 16u + q.off_tp)); }
+__device__ __forceinline__ float2 ld_od1(const StreamSlice &q, uint32_t i) { return *reinterpret_cast<const float2 *>(q.base + (i * 8u + q.off_od1)); }
 __device__ __forceinline__ void store_ray(const StreamSlice &q, uint32_t slot, vec3 o, vec3 d, vec3 thr, uint32_t word) {
-    *reinterpret_cast<float4 *>(q.od0 + slot * 16u) = make_float4(o.x, o.y, o.z, d.x);
-    *reinterpret_cast<float2 *>(q.od1 + slot * 8u) = make_float2(d.y, d.z);
-    *reinterpret_cast<float4 *>(q.tp + slot * 16u) = make_float4(thr.x, thr.y, thr.z, __uint_as_float(word));
+    *reinterpret_cast<float4 *>(q.base + slot * 16u) = make_float4(o.x, o.y, o.z, d.x);
+    *reinterpret_cast<float2 *>(q.base + (slot * 8u + q.off_od1)) = make_float2(d.y, d.z);
+    *reinterpret_cast<float4 *>(q.base + (slot * 16u + q.off_tp)) = make_float4(thr.x, thr.y, thr.z, __uint_as_float(word));
 }
 // a ray of a stream's slice (read once per level; non-temporal loads / stores were tried: loads +0.2 %, stores -6 % - the
 // next level reads what this one wrote from L2)
 __device__ __forceinline__ void load_ray_slice(const StreamSlice &q, uint32_t i, vec3 &o, vec3 &d, vec3 &thr, uint32_t &word) {
-    const float4 a = *reinterpret_cast<const float4 *>(q.od0 + i * 16u);
-    const float4 tp = *reinterpret_cast<const float4 *>(q.tp + i * 16u);
-    const float2 c = *reinterpret_cast<const float2 *>(q.od1 + i * 8u);
+    const float4 a = ld_od0(q, i);
+    const float4 tp = ld_tp(q, i);
+    const float2 c = ld_od1(q, i);
     o = mk(a.x, a.y, a.z);
     d = mk(a.w, c.x, c.y);
     thr = mk(tp.x, tp.y, tp.z);
@@ -103,14 +103,14 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams F, RayQueue q, 
                                                      uint32_t cap, uint32_t s0, uint32_t s_here, uint32_t m) {
     // stream b = its pixels (stream_pixel) x samples [s0, s0+s_here); lane order: pixel fastest
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
-    const size_t base = (size_t)b * cap;
+    const StreamSlice qs = slice_of(q, b, cap);
     const uint32_t mb = stream_pixel_count(F.npix, F.n_streams, b);  // <= m
     const uint32_t n = mb * s_here;
     for (uint32_t g = tid; g < n; g += kBlock) {
         const uint32_t pl = stream_pixel(F.n_streams, b, g % mb);
         const uint32_t s = s0 + g / mb;
         const PathRay r = primary_ray<PROBE>(F, global_pixel(F, pl), s);
-        store_ray(q, base + g, r.o, r.d, r.thr, pack_word(g % mb, g / mb, PROBE ? F.depth0 : 0u, 1u));
+        store_ray(qs, g, r.o, r.d, r.thr, pack_word(g % mb, g / mb, PROBE ? F.depth0 : 0u, 1u));
     }
     if (tid == 0) cnt0[b] = n;
 }
@@ -133,11 +133,12 @@ __global__ __launch_bounds__(BVH ? kBlockBvh : kBlock, BVH ? 5 : 1) void k_inter
                                                       unsigned long long *__restrict__ blk_rays) {
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
     const uint32_t n = cnt[b];
-    const size_t base = (size_t)b * cap;
+    const size_t base = (size_t)b * cap;  // (of the hit records)
+    const StreamSlice qs = slice_of(q, b, cap);
     if (!BVH) {
         for (uint32_t i = tid; i < n; i += blockDim.x) {
-            const float4 a = q.od0[base + i];
-            const float2 c = q.od1[base + i];
+            const float4 a = ld_od0(qs, i);
+            const float2 c = ld_od1(qs, i);
             const HitRec h = intersect_scene_dev<false>(S, mk(a.x, a.y, a.z), mk(a.w, c.x, c.y), dyn_lds);
             hit[base + i] = make_float2(h.t, __int_as_float(h.id));
         }
@@ -172,8 +173,8 @@ __global__ __launch_bounds__(BVH ? kBlockBvh : kBlock, BVH ? 5 : 1) void k_inter
             h.t = 0.0f;
             h.id = -1;
             if (i < n) {
-                const float4 a = q.od0[base + i];
-                const float2 c = q.od1[base + i];
+                const float4 a = ld_od0(qs, i);
+                const float2 c = ld_od1(qs, i);
                 o = mk(a.x, a.y, a.z);
                 d = mk(a.w, c.x, c.y);
                 h = intersect_scene_dev<true, true>(S, o, d, dyn_lds, &want);
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_intersect_cand(DevScene S, RayQue
             __syncthreads();
         }
     }
-    const StreamSlice qin = slice_of(q, (size_t)b * cap);
+    const StreamSlice qin = slice_of(q, b, cap);
     float2 *const hit_b = hit + (size_t)b * cap;
     CandRing ring;
     ring.head = 0u;
@@ -251,8 +252,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_intersect_cand(DevScene S, RayQue
         if (it < n_chunks) {
             vec3 o = mk(0.0f, 0.0f, 0.0f), d = o;
             if (cur_valid) {
-                const float4 a = *reinterpret_cast<const float4 *>(qin.od0 + i * 16u);
-                const float2 c = *reinterpret_cast<const float2 *>(qin.od1 + i * 8u);
+                const float4 a = ld_od0(qin, i);
+                const float2 c = ld_od1(qin, i);
                 o = mk(a.x, a.y, a.z);
                 d = mk(a.w, c.x, c.y);
             }
@@ -316,11 +317,12 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, ShadeParams F, Ray
     float2 n_hr = make_float2(0.0f, __int_as_float(-1));
     float4 n_a = make_float4(0, 0, 0, 0), n_tp = n_a;
     float2 n_c = make_float2(0, 0);
+    const StreamSlice sin = slice_of(qin, b, cap), sout = slice_of(qout, b, cap);
     if (tid < n) {
         n_hr = hit[base + tid];
-        n_a = qin.od0[base + tid];
-        n_c = qin.od1[base + tid];
-        n_tp = qin.tp[base + tid];
+        n_a = ld_od0(sin, tid);
+        n_c = ld_od1(sin, tid);
+        n_tp = ld_tp(sin, tid);
     }
     for (uint32_t j0 = 0; j0 < n; j0 += kBlock) {  // uniform trip count: every lane reaches the ballots
         const uint32_t i = j0 + tid;
@@ -330,9 +332,9 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, ShadeParams F, Ray
         const uint32_t i_next = i + kBlock;
         if (i_next < n) {
             n_hr = hit[base + i_next];
-            n_a = qin.od0[base + i_next];
-            n_c = qin.od1[base + i_next];
-            n_tp = qin.tp[base + i_next];
+            n_a = ld_od0(sin, i_next);
+            n_c = ld_od1(sin, i_next);
+            n_tp = ld_tp(sin, i_next);
         }
         ShadeOut so;
         so.n_rays = 0;
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, ShadeParams F, Ray
         if (so.n_rays >= 1) {
             const uint32_t slot = wbase + lane_prefix(m1);
             if (slot < cap)
-                store_ray(qout, base + slot, so.x, so.d0, so.thr0,
+                store_ray(sout, slot, so.x, so.d0, so.thr0,
                           pack_word(word_pix(word), word_sample(word), meta_depth(so.meta0), meta_branch(so.meta0)));
             else
                 overflow = true;
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, ShadeParams F, Ray
         if (so.n_rays == 2) {
             const uint32_t slot = wbase + c1 + lane_prefix(m2);
             if (slot < cap)
-                store_ray(qout, base + slot, so.x, so.d1, so.thr1,
+                store_ray(sout, slot, so.x, so.d1, so.thr1,
                           pack_word(word_pix(word), word_sample(word), meta_depth(so.meta1), meta_branch(so.meta1)));
             else
                 overflow = true;
@@ -492,8 +494,8 @@ __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, R
         append(so, word);
     };
     for (uint32_t depth = 0; depth < (uint32_t)kMaxDepth && n != 0u; ++depth) {
-        const StreamSlice qin = slice_of((depth & 1u) ? q1 : q0, base);  // level 0 is never stored
-        qout = slice_of((depth & 1u) ? q0 : q1, base);
+        const StreamSlice qin = slice_of((depth & 1u) ? q1 : q0, b, cap);  // level 0 is never stored
+        qout = slice_of((depth & 1u) ? q0 : q1, b, cap);
         __syncthreads();  // level `depth` of the stream is complete and visible to the whole workgroup
         // the other counter was last read before this barrier (end of the level before) and is next added to after
         // the next one
@@ -510,9 +512,9 @@ __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, R
                     in = primary_ray<PROBE>(F, lds_pix[pj], s0 + sj);
                     word = pack_word(pj, sj, PROBE ? F.depth0 : 0u, 1u);
                 } else {
-                    const float4 a = *reinterpret_cast<const float4 *>(qin.od0 + i * 16u);
-                    const float4 tp = *reinterpret_cast<const float4 *>(qin.tp + i * 16u);
-                    const float2 c = *reinterpret_cast<const float2 *>(qin.od1 + i * 8u);
+                    const float4 a = ld_od0(qin, i);
+                    const float4 tp = ld_tp(qin, i);
+                    const float2 c = ld_od1(qin, i);
                     in.o = mk(a.x, a.y, a.z);
                     in.d = mk(a.w, c.x, c.y);
                     in.thr = mk(tp.x, tp.y, tp.z);
@@ -797,9 +799,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
     ring.head = 0u;
     ring.count = 0u;
     for (uint32_t depth = 0; depth < (uint32_t)kMaxDepth && n != 0u; ++depth) {
-        qin = slice_of((depth & 1u) ? q1 : q0, base);  // level 0 is never stored
+        qin = slice_of((depth & 1u) ? q1 : q0, b, cap);  // level 0 is never stored
         level = depth;
-        qout = slice_of((depth & 1u) ? q0 : q1, base);
+        qout = slice_of((depth & 1u) ? q0 : q1, b, cap);
         PT_PHASE(kPhBarrier);
         __syncthreads();  // level `depth` of the stream is complete and visible (and, the first time, the staged records)
         PT_PHASE(kPhOther);
@@ -1052,7 +1054,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_bvh(DevScene S, FrameParams 
     for (uint32_t g = tid; g < n; g += kBlock) {  // level 0: render_pixel's rays (pixel g % mb, sample s0 + g / mb)
         const uint32_t pj = g % mb, sj = g / mb;
         const PathRay r = primary_ray<PROBE>(F, lds_pix[pj], s0 + sj);
-        store_ray(q0, base + g, r.o, r.d, r.thr, pack_word(pj, sj, PROBE ? F.depth0 : 0u, 1u));
+        store_ray(slice_of(q0, b, cap), g, r.o, r.d, r.thr, pack_word(pj, sj, PROBE ? F.depth0 : 0u, 1u));
     }
     uint32_t n_park = 0;  // wave-uniform
     StreamSlice qin{}, qout{};
@@ -1083,9 +1085,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_bvh(DevScene S, FrameParams 
         }
     };
     auto load_ray = [&](uint32_t i, PathRay &in, uint32_t &word) {
-        const float4 a = *reinterpret_cast<const float4 *>(qin.od0 + i * 16u);
-        const float4 tp = *reinterpret_cast<const float4 *>(qin.tp + i * 16u);
-        const float2 c = *reinterpret_cast<const float2 *>(qin.od1 + i * 8u);
+        const float4 a = ld_od0(qin, i);
+        const float4 tp = ld_tp(qin, i);
+        const float2 c = ld_od1(qin, i);
         in.o = mk(a.x, a.y, a.z);
         in.d = mk(a.w, c.x, c.y);
         in.thr = mk(tp.x, tp.y, tp.z);
@@ -1120,8 +1122,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_bvh(DevScene S, FrameParams 
         shade_and_append(valid, in, word, h);
     };
     for (uint32_t depth = 0; depth < (uint32_t)kMaxDepth && n != 0u; ++depth) {
-        qin = slice_of((depth & 1u) ? q1 : q0, base);
-        qout = slice_of((depth & 1u) ? q0 : q1, base);
+        qin = slice_of((depth & 1u) ? q1 : q0, b, cap);
+        qout = slice_of((depth & 1u) ? q0 : q1, b, cap);
         __syncthreads();  // level `depth` of the stream is complete and visible to the whole workgroup
         if (tid == 0) s_tail_p[(depth + 1u) & 1u] = 0u;  // two-counter protocol of k_pass
         tail_p = s_tail_p + (depth & 1u);

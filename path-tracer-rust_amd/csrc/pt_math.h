@@ -131,7 +131,15 @@ PT_HD u32x4 draw_block(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t 
     c.b = sample;
     c.c = tag;
     c.d = 0u;
-    return philox4x32<kPhiloxRounds>(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // The key is the same for every draw of a kernel, so the compiler hoists the whole key schedule (k + r * W, fourteen
+    // scalars) out of the kernels' loops - and, the pass kernels being short of SGPRs, parks it in VGPR lanes: fourteen
+    // v_readlane per block, VALU issue slots each.  An opaque pass through the scalar registers keeps the schedule where it
+    // is used: fourteen s_add per block, which issue beside the vector instructions.
+    asm volatile("" : "+s"(k0), "+s"(k1));
+#endif
+    return philox4x32<kPhiloxRounds>(c, k0, k1);
 }
 
 // ---- sinf / cosf for |y| < 120: glibc (ARM optimized-routines) algorithm, evaluated in binary64
