@@ -350,8 +350,9 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
             m = best_m;
         }
         K = (uint32_t)((npix + m - 1) / m);
-        // a primary ray has at most 4 descendants alive at one depth (two refract splits, mod.rs:760)
-        const uint64_t cap64 = (4ull * m * spp_pass + kBlock - 1) / kBlock * kBlock;
+        // a primary ray has at most 4 descendants alive at one depth (two refract splits, mod.rs:760); k_pass_cand gives each
+        // of its four waves a quarter of the slice and ceil(n / 4) of the stream's n primaries: 4 * ceil(n / 4) <= n + 3
+        const uint64_t cap64 = (4ull * m * spp_pass + 16u + kBlock - 1) / kBlock * kBlock;
         // (slot indices are 32-bit over the whole queue, byte offsets 32-bit inside a stream's slice of cap * 40 bytes)
         if (cap64 * K > 0xffffffffull / 2 || cap64 * kRayBytes > 0xffffffffull) {
             if (spp_pass > 1u && !cfg->rays_per_pass) {  // (a default this large only on a device with > 680 GB)

@@ -625,7 +625,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
     phase_begin(&ph_t0, &ph_r0);
 #endif
     for (uint32_t k = tid; k < 3u * m; k += kBlock) lds_acc[k] = 0ull;
-    if (tid == 0) s_tail_p[0] = s_tail_p[1] = 0u;
+    if (tid == 0) s_tail_p[0] = s_tail_p[1] = 0u;  // (here: the workgroup's ray count, u64)
     // per stream pixel: framebuffer index (the RNG counter), and its column and row from the bottom (render_pixel's x, y,
     // mod.rs:805-806): two divisions here instead of two per primary ray
     uint32_t *lds_pix = s_tail_p + 4;
@@ -638,8 +638,18 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
     }
     // ray g of level 0 is (pixel g % mb of the stream, sample g / mb); a lane's rays are 256 apart, so its (pixel, sample)
     // advance by (256 % mb, 256 / mb) with a carry - no division per trip
-    const uint32_t step_q = kBlock / mb, step_r = kBlock % mb;
-    uint32_t gen_pj = tid % mb, gen_sj = tid / mb;
+    // THE WAVES OF A WORKGROUP DO NOT WAIT FOR EACH OTHER: every wave walks a quarter of the stream on its own - a contiguous
+    // quarter of the stream's level-0 rays, and from then on its own quarter of the stream's queue slice (cap / 4 slots: four
+    // times its primaries, the host leaves room for the rounding) - so the level boundaries need no workgroup barrier (where
+    // the four waves used to wait 3.5 % of their lifetime on cornell and 9 % on mesh.json, whose walks differ from wave to
+    // wave), and the slice's tail is a scalar register of the wave instead of an LDS counter behind an atomic.
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t cap_w = cap >> 2;
+    const uint32_t n0 = mb * s_here;                  // level-0 rays of the stream
+    const uint32_t quarter = (n0 + 3u) >> 2;               // ... of a wave (the last may have fewer)
+    const uint32_t base0 = wv * quarter < n0 ? wv * quarter : n0;
+    const uint32_t step_q = 64u / mb, step_r = 64u % mb;
+    uint32_t gen_pj = (base0 + lane) % mb, gen_sj = (base0 + lane) / mb;
     CandLds cand;
     const SurfRec *surf_lds = nullptr;
     uint32_t surf_head = 0u;
@@ -691,7 +701,6 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
         wq.cap = (uint32_t)((pass_cand_queue_bytes(S) - kWalkQueueHeader) / 8u);
         if (S.walk_queue_cap >= 128u && S.walk_queue_cap < wq.cap) wq.cap = S.walk_queue_cap;
     }
-    const size_t base = (size_t)b * cap;
     ShadeParams P;
     P.idx_begin = F.idx_begin;
     P.npix = F.npix;
@@ -706,21 +715,20 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
     P.k_begin = F.k_begin;
     bool overflow = false;
     unsigned long long total = 0ull;
-    uint32_t n = mb * s_here;  // rays of the current level
+    uint32_t n = (n0 - base0) < quarter ? (n0 - base0) : quarter;  // this wave's rays of the current level
     StreamSlice qout{};
-    uint32_t *tail_p = nullptr;
+    uint32_t tail = 0u;  // wave-uniform: rays this wave has appended to the next level
     auto append = [&](const ShadeOut &so, uint32_t word) {
         PT_PHASE(kPhAppend);
         const uint64_t m1 = __builtin_amdgcn_ballot_w64(so.n_rays >= 1);
         const uint64_t m2 = __builtin_amdgcn_ballot_w64(so.n_rays == 2);
         const uint32_t c1 = (uint32_t)__builtin_popcountll(m1), c2 = (uint32_t)__builtin_popcountll(m2);
         if ((c1 + c2) == 0u) return;  // wave-uniform
-        uint32_t wbase = 0;
-        if (lane == 0u) wbase = atomicAdd(tail_p, c1 + c2);
-        wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+        const uint32_t wbase = tail;
+        tail += c1 + c2;
         if (so.n_rays >= 1) {
             const uint32_t slot = wbase + lane_prefix(m1);
-            if (slot < cap)
+            if (slot < cap_w)
                 store_ray(qout, slot, so.x, so.d0, so.thr0,
                           pack_word(word_pix(word), word_sample(word), meta_depth(so.meta0), meta_branch(so.meta0)));
             else
@@ -728,7 +736,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
         }
         if (so.n_rays == 2) {
             const uint32_t slot = wbase + c1 + lane_prefix(m2);
-            if (slot < cap)
+            if (slot < cap_w)
                 store_ray(qout, slot, so.x, so.d1, so.thr1,
                           pack_word(word_pix(word), word_sample(word), meta_depth(so.meta1), meta_branch(so.meta1)));
             else
@@ -775,7 +783,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
             const uint32_t i = p_idx[e];
             PathRay in;
             if (level == 0u) {
-                const uint32_t pj = i % mb, sj = i / mb;
+                const uint32_t pj = (base0 + i) % mb, sj = (base0 + i) / mb;
                 in = primary_ray<PROBE>(F, lds_pix[pj], s0 + sj);
                 word = pack_word(pj, sj, PROBE ? F.depth0 : 0u, 1u);
             } else {
@@ -798,15 +806,14 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
     CandRing ring;
     ring.head = 0u;
     ring.count = 0u;
-    for (uint32_t depth = 0; depth < (uint32_t)kMaxDepth && n != 0u; ++depth) {
-        qin = slice_of((depth & 1u) ? q1 : q0, b, cap);  // level 0 is never stored
+    PT_PHASE(kPhBarrier);
+    __syncthreads();  // accumulators, pixel tables and staged records are in place
+    PT_PHASE(kPhOther);
+    for (uint32_t depth = 0; depth < (uint32_t)kMaxDepth && n != 0u; ++depth) {  // (wave-uniform)
+        qin = slice_of((depth & 1u) ? q1 : q0, b * 4u + wv, cap_w);  // level 0 is never stored
         level = depth;
-        qout = slice_of((depth & 1u) ? q0 : q1, b, cap);
-        PT_PHASE(kPhBarrier);
-        __syncthreads();  // level `depth` of the stream is complete and visible (and, the first time, the staged records)
-        PT_PHASE(kPhOther);
-        if (tid == 0) s_tail_p[(depth + 1u) & 1u] = 0u;
-        tail_p = s_tail_p + (depth & 1u);
+        qout = slice_of((depth & 1u) ? q0 : q1, b * 4u + wv, cap_w);
+        tail = 0u;
         // (Carrying a level's partial chunk over to the next level instead of tracing it half empty - rays keep their own depth
         // in the bookkeeping word, so a level may mix depths - was built and measured: the partial chunks are 4.8 % of all
         // chunk trips' lanes (profiles/r03_k_pass_cand_phase_budget.json), but every carried ray lengthens its stream by a
@@ -819,14 +826,14 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
         // - 39.5 KB, 18 KB of it the glass-deferral buffers - allows four workgroups per CU; without deferral five waves beat
         // four, 40.7 against 39.5, but not four with deferral, 40.3; with deferral in 32 KB - 64 entries of 44 bytes - the
         // kernel spills 8 values in the loop: 37.5.)
-        const uint32_t n_chunks = (n + kBlock - 1u) / kBlock;
+        const uint32_t n_chunks = (n + 63u) >> 6;
         total += n;
         vec3 prev_thr = mk(0.0f, 0.0f, 0.0f);  // what the ray started in the trip before still needs from registers
         uint32_t prev_word = 0;
         bool prev_valid = false;
         for (uint32_t it = 0; it <= n_chunks; ++it) {  // uniform trip count; the last trip only finishes chunk n_chunks - 1
             const uint32_t par = it & 1u;
-            const uint32_t i = it * kBlock + tid;
+            const uint32_t i = (it << 6) | lane;
             const bool cur_valid = it < n_chunks && i < n;
             vec3 cur_thr = mk(0.0f, 0.0f, 0.0f);
             uint32_t word = 0;
@@ -927,7 +934,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
                     if (mw != 0ull) {
                         if (park) {
                             const uint32_t e = n_park + lane_prefix(mw);
-                            p_idx[e] = (it - 1u) * kBlock + tid;
+                            p_idx[e] = ((it - 1u) << 6) | lane;
                             p_key[e] = park_key;
                         }
                         n_park += (uint32_t)__builtin_popcountll(mw);
@@ -968,15 +975,17 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
             shade_deferred(lane, lane < n_defer);
             n_defer = 0u;
         }
-        PT_PHASE(kPhBarrier);
-        __syncthreads();  // every append of this level is counted
-        PT_PHASE(kPhOther);
-        const uint32_t tail = *tail_p;
-        n = tail < cap ? tail : cap;
+        // the wave reads back what it has stored itself: its stores are ordered before its loads of the next level
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        n = tail < cap_w ? tail : cap_w;
     }
     if (overflow) atomicOr(flags, 1u);
-    __syncthreads();
-    if (tid == 0) blk_rays[b] += total;
+    if (lane == 0u) atomicAdd(reinterpret_cast<unsigned long long *>(s_tail_p), total);
+    PT_PHASE(kPhBarrier);
+    __syncthreads();  // every wave of the workgroup is done: the accumulators are complete
+    PT_PHASE(kPhOther);
+    if (tid == 0) blk_rays[b] += *reinterpret_cast<unsigned long long *>(s_tail_p);
     const size_t plane = (size_t)F.n_streams * m;
     for (uint32_t k = tid; k < 3u * mb; k += kBlock) {
         const uint32_t c = k / mb, p = k - c * mb;
