@@ -77,6 +77,8 @@ struct Tuning {
                                // the candidate scan with parked walks (k_pass_cand<.., BVH>)
     uint32_t leaf_quorum = 12; // PT_LEAF_QUORUM: lanes on a leaf that send a walking wave to the triangle code
     uint64_t streams = 0;      // PT_STREAMS: ray streams per pass (0 = derived from the frame)
+    uint32_t per_stream = 0;   // PT_PER_STREAM: primary rays per stream and pass that k_pass_cand's stream count aims at (0 = default)
+    uint64_t rays_per_pass = 0;  // PT_RAYS_PER_PASS: the default of pt_config.rays_per_pass (probes; 0 = the library's)
     uint32_t debug = 0;
 };
 static Tuning read_tuning() {
@@ -94,6 +96,8 @@ static Tuning read_tuning() {
     t.leaf_quorum = (uint32_t)num("PT_LEAF_QUORUM", 12);
     const long long st = num("PT_STREAMS", 0);
     t.streams = st > 0 ? (uint64_t)st : 0;
+    t.per_stream = (uint32_t)num("PT_PER_STREAM", 0);
+    t.rays_per_pass = (uint64_t)num("PT_RAYS_PER_PASS", 0);
 #ifdef PT_ALLOW_DEBUG
     t.debug = (uint32_t)num("PT_DEBUG", 0);
 #endif
@@ -281,20 +285,28 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
                      const volatile uint8_t *cancel, pt_progress_fn cb, void *user, pt_stats *stats) {
     FrameParams F = frame;
     const uint64_t npix = F.npix;
-    // 96 Mi primary rays per pass by default: 36 GB of ray queues (two containers x 4 slots per primary ray x 40 B) of the
-    // 288 GB of HBM.  Fewer, longer launches: cornell 1024x768 @4096 spp 32 Mi 35.7, 48 Mi 35.7, 64 Mi 36.2, 96 Mi 36.4 G
-    // bounces/s (a launch ends with its slowest streams; 32 launches per frame instead of 98).
+    // Level-by-level forms (k_pass, k_pass_bvh, the separate kernels): 96 Mi primary rays per pass by default, 36 GB of ray
+    // queues (two containers x 4 slots per primary ray x 40 B) of the 288 GB of HBM - fewer, longer launches: cornell 1024x768
+    // @4096 spp 32 Mi 35.7, 48 Mi 35.7, 64 Mi 36.2, 96 Mi 36.4 G bounces/s (a launch ends with its slowest streams).
+    // k_pass_cand (`stack_form`) keeps a wave's waiting rays on a stack of at most kWaveStackMax slots whatever the pass holds:
+    // its passes are sized by TIME - 384 Mi primary rays, about 0.1 s between two looks at the cancel flag (the reference
+    // polls it every 100 ms, mod.rs:947-958) - and its memory is the streams' (K x 4 waves x stack x 40 B: 10.7 GB for 32 Ki
+    // streams at most; small passes need less: 4 x pow2(primaries per wave) slots per stream).
     // The default is what the DEVICE can give: 85 % of the free memory (plus what this context's queues hold already),
     // divided by the contexts that share the device in this call (PT_FLAG_PIPELINES, ranks of pt_render_multi on one GPU),
-    // or pt_ctx_set_memory_budget's figure - at 352 B per primary ray (queues + hit records of the three-kernel form); and
-    // whatever was asked for, a failed allocation halves the pass and tries again: passes only change how the samples are
-    // batched, never the image.
+    // or pt_ctx_set_memory_budget's figure - at 352 B per primary ray for the level-by-level forms (queues + hit records of
+    // the three-kernel form), by the streams' stacks for k_pass_cand; and whatever was asked for, a failed allocation halves
+    // the pass and tries again: passes only change how the samples are batched, never the image.
     const bool bvh_ok = c->scene.n_bvh_nodes == 0u || (!(c->scene.bvh_in_lds & 1u) && c->tune.pass_bvh);
     const bool one_kernel = bvh_ok && c->tune.pass_kernel && !(cfg->flags & PT_FLAG_SEPARATE_KERNELS);
     const bool needs_hits = !one_kernel;
-    uint64_t want = cfg->rays_per_pass;
+    const bool stack_form = one_kernel && c->scene.cand_scan != 0u;
+    const bool stack_park = stack_form && c->scene.n_bvh_nodes != 0u;  // container 1: the waves' parked rays
+    uint64_t want = cfg->rays_per_pass ? cfg->rays_per_pass : c->tune.rays_per_pass;
+    size_t stack_budget = 0;  // stack_form, default pass size: what the streams' stacks may take
     if (!want) {
-        want = 96u << 20;
+        const uint64_t dflt = stack_form ? (384u << 20) : (96u << 20);
+        want = dflt;
         size_t held = c->hit.bytes();
         for (int w = 0; w < 2; ++w) held += c->q_buf[w].bytes();
         size_t avail = c->mem_budget;
@@ -302,11 +314,12 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
             size_t mem_free = 0, mem_total = 0;
             if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess) avail = (size_t)((double)(mem_free + held) * 0.85) / (c->mem_share ? c->mem_share : 1u);
         }
-        if (avail) {
+        if (avail && !stack_form) {
             const uint64_t fit = avail / 352u;
             if (fit < want) want = fit;
         }
-        if (c->mem_share > 1u && want > (96u << 20) / c->mem_share) want = (96u << 20) / c->mem_share;  // (co-resident contexts also share the chip)
+        if (stack_form) stack_budget = avail;
+        if (c->mem_share > 1u && want > dflt / c->mem_share) want = dflt / c->mem_share;  // (co-resident contexts also share the chip)
         if (want < npix) want = npix;  // one sample per pixel and pass at least
     }
     uint32_t spp_pass = 0, m = 0, K = 0, cap = 0;
@@ -323,7 +336,10 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
         // 7.3, 8192 7.6, 16384 7.0)
         // (candidate scan, four waves per SIMD: 12288 streams 35.8, 16384 35.4, 8192 32.2, 24576 33.7 G bounces/s)
         // (candidate scan with walks, mesh.json: 24576 streams 19.8, 26624 20.5, 28672 20.1, 30720 20.3, 32768 19.9 G bounces/s)
-        const uint64_t per_stream = c->scene.n_bvh_nodes != 0u ? (c->scene.cand_scan ? 3840u : 4096u) : (c->scene.cand_scan ? 2688u : 2048u);
+        // (k_pass_cand's waves run without levels: a wave's first and last trips - the stack fills, the last rays die - are
+        // the only ones that are not full, so its streams are long)
+        const uint64_t per_stream = stack_form ? (uint64_t)(c->tune.per_stream ? c->tune.per_stream : 12288u)
+                                               : (c->scene.n_bvh_nodes != 0u ? 4096u : 2048u);
         uint64_t k_target = ((uint64_t)npix * spp_pass + per_stream - 1u) / per_stream;
         if (k_target < 2048u) k_target = 2048u;
         if (c->tune.streams) k_target = c->tune.streams;
@@ -352,7 +368,20 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
         K = (uint32_t)((npix + m - 1) / m);
         // a primary ray has at most 4 descendants alive at one depth (two refract splits, mod.rs:760); k_pass_cand gives each
         // of its four waves a quarter of the slice and ceil(n / 4) of the stream's n primaries: 4 * ceil(n / 4) <= n + 3
-        const uint64_t cap64 = (4ull * m * spp_pass + 16u + kBlock - 1) / kBlock * kBlock;
+        uint64_t cap64 = (4ull * m * spp_pass + 16u + kBlock - 1) / kBlock * kBlock;
+        // k_pass_cand keeps a wave's waiting rays on a stack of at most kWaveStackMax slots (a quarter of the stream's slice
+        // per wave, a power of two of at least 128 slots - the parking area of a wave's walks has the same size)
+        if (stack_form) {
+            const uint64_t need_w = (uint64_t)m * spp_pass + 8u;
+            uint64_t cap_w = 128u;
+            while (cap_w < need_w && cap_w < kWaveStackMax) cap_w *= 2u;
+            cap64 = 4u * cap_w;
+            if (stack_budget && queue_bytes(K, (uint32_t)cap64) + (stack_park ? queue_bytes(K, 4u * kWaveParkCap) : 0u) > stack_budget &&
+                spp_pass > 1u) {  // the default pass does not fit the budget: smaller passes have fewer streams or smaller stacks
+                want = (uint64_t)npix * (spp_pass / 2u);
+                continue;
+            }
+        }
         // (slot indices are 32-bit over the whole queue, byte offsets 32-bit inside a stream's slice of cap * 40 bytes)
         if (cap64 * K > 0xffffffffull / 2 || cap64 * kRayBytes > 0xffffffffull) {
             if (spp_pass > 1u && !cfg->rays_per_pass) {  // (a default this large only on a device with > 680 GB)
@@ -365,7 +394,9 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
         cap = (uint32_t)cap64;
         const size_t slots = (size_t)K * cap;
         int rc = PT_OK;
-        for (int w = 0; w < 2 && !rc; ++w) rc = c->q_buf[w].ensure(queue_bytes(K, cap), true);
+        rc = c->q_buf[0].ensure(queue_bytes(K, cap), true);
+        if (!rc && !stack_form) rc = c->q_buf[1].ensure(queue_bytes(K, cap), true);
+        if (!rc && stack_park) rc = c->q_buf[1].ensure(queue_bytes(K, 4u * kWaveParkCap), true);
         // scenes without BVH meshes run a pass as one launch (k_pass), BVH scenes as k_pass_bvh unless their nodes are staged
         // in LDS; PT_FLAG_SEPARATE_KERNELS / PT_PASS_KERNEL=0 / PT_PASS_BVH=0 keep the three-kernel form (A/B, profiling).
         // Only that form needs the hit records: k_pass keeps hits in registers.
@@ -508,8 +539,8 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
         }
         stats->ms_intersect = mi;
     }
-    if (flags & 1u) {
-        set_error("ray stream overflow");
+    if (flags & 3u) {
+        set_error((flags & 2u) ? "ray stream slices too small for k_pass_cand's wave stacks" : "ray stream overflow");
         return PT_ERR_OVERFLOW;
     }
     if (cancelled) {
@@ -845,7 +876,13 @@ int pt_device_malloc(int device, size_t bytes, void **out) {
         return PT_ERR_NO_DEVICE;
     }
     HIP_TRY(hipSetDevice(device));
-    HIP_TRY(hipMalloc(out, bytes ? bytes : 1));
+    const hipError_t e = hipMalloc(out, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // reported here: a refused allocation must not show up again as the next frame's error
+        *out = nullptr;
+        set_error(std::string("hipMalloc of ") + std::to_string(bytes) + " bytes: " + hipGetErrorString(e));
+        return PT_ERR_HIP;
+    }
     return PT_OK;
 }
 

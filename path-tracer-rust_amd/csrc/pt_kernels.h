@@ -19,6 +19,8 @@ struct RayQueue {
     char *buf;
 };
 constexpr uint32_t kRayBytes = 40;
+constexpr uint32_t kWaveParkCap = 128;    // parked rays of a wave (k_pass_cand with walks: 63 left over + 64 new at most)
+constexpr uint32_t kWaveStackMax = 2048;  // slots of a wave's ray stack (k_pass_cand: a quarter of the stream's slice)
 inline size_t queue_bytes(size_t K, uint32_t cap) { return K * (size_t)cap * kRayBytes; }
 
 // one whole pass of a scene without BVH meshes in one launch (see k_pass)

@@ -57,6 +57,8 @@ constexpr size_t kCandWaveBytes = 128u * 16u + 128u * 8u + 128u * 8u + kCandQueu
 __host__ __device__ constexpr size_t pass_lds_cand_bytes() { return (size_t)(kBlock / 64u) * kCandWaveBytes; }
 static_assert(kCandWaveBytes % 16u == 0u, "per-wave areas stay 16-byte aligned");
 
+// a wave-uniform value, said so to the compiler (loop-carried counters of the pass kernels otherwise end up in VGPRs)
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint32_t lane_prefix(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
@@ -547,7 +549,7 @@ __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, R
                     dbuf[kDeferCap + e] = make_float4(in.d.y, in.d.z, in.thr.x, in.thr.y);
                     dbuf[2u * kDeferCap + e] = make_float4(in.thr.z, __uint_as_float(word), h.t, __int_as_float(h.id));
                 }
-                n_defer += (uint32_t)__builtin_popcountll(md);
+                n_defer = rfl(n_defer + (uint32_t)__builtin_popcountll(md));
             }
             if (DEFER && n_defer >= 64u) {  // wave-uniform
                 n_defer -= 64u;
@@ -590,7 +592,7 @@ __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, R
 // shaded and appended.
 // LDS of that form, between the per-wave candidate areas and the staged records:
 //   [per wave: walk queue (pass_cand_queue_bytes)][per wave: park u32 idx x 128, u64 key x 128][per wave: u64 key x 64]
-constexpr uint32_t kCandParkCap = 128;  // 63 left over + 64 new at most
+constexpr uint32_t kCandParkCap = kWaveParkCap;  // 63 left over + 64 new at most
 // per wave: the walk queue (header + 8-byte entries: box tests from one end, leaves from the other), which is also where
 // the depth-first stacks (DevScene.bvh_stack entries x 64 lanes x u16, or u32 when a tree has 32 768 nodes or leaves) and
 // the leaf list of the rare second walk live
@@ -713,35 +715,56 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
     P.chunk_first = F.chunk_first;
     P.chunk_step = F.chunk_step;
     P.k_begin = F.k_begin;
-    bool overflow = false;
+    bool overflow = false;  // wave-uniform
     unsigned long long total = 0ull;
-    uint32_t n = (n0 - base0) < quarter ? (n0 - base0) : quarter;  // this wave's rays of the current level
-    StreamSlice qout{};
-    uint32_t tail = 0u;  // wave-uniform: rays this wave has appended to the next level
+    // THE WAVE'S RAY STACK.  Rays that wait for their next bounce live on a stack of the wave in global memory (the wave's
+    // quarter of the stream's slice of container 0): the wave pops the 64 most recent ones whenever at least 64 wait and
+    // starts 64 new primary rays otherwise - there are no levels, rays of every depth share a chunk (each carries its own
+    // depth in its bookkeeping word), so that until a wave's very last rays every chunk, every exact batch, every batch of
+    // glass hits and every walk session of 64 parked rays runs full (with levels every level ended in a partial chunk, a
+    // flushing trip and - with walks - a partial session: half of mesh.json's sessions), and the live rays of a wave are a
+    // few hundred (depth first), which stay in L2.  A slot that is popped may be pushed over in the same trip: the vector
+    // memory operations of one wave are performed in order.  (A ring - first in, first out, so that a pop never reads what the
+    // trip before has just stored - was measured: the ring's positions wander through all its slots and the waves' live rays
+    // no longer stay in L2; cornell 40.8 against 42.6 G bounces/s, mesh.json 23.0 against 25.8.)
+    // Room: a waiting ray of depth 1 can have two descendants waiting at a time, deeper ones one, a primary ray four (two
+    // refract splits, mod.rs:760).  `phi` bounds what the rays the wave holds anywhere (stack, chunk in flight, parked,
+    // deferred) can ever put on the stack at once; new primaries (at most 4 x 64 more) are started only while that fits.
+    const uint32_t room = cap_w < kWaveStackMax ? cap_w : kWaveStackMax;
+    const bool room_for_all = 4u * quarter + 3u <= room;  // everything this wave will ever trace fits: nothing to watch
+    StreamSlice qs;
+    qs.base = q0.buf + (size_t)(b * 4u + wv) * cap_w * kRayBytes;
+    qs.off_tp = room * 16u;
+    qs.off_od1 = room * 32u;
+    StreamSlice qpark{};  // BVH: the parked rays of the wave (container 1)
+    if (BVH) {
+        qpark.base = q1.buf + (size_t)(b * 4u + wv) * kCandParkCap * kRayBytes;
+        qpark.off_tp = kCandParkCap * 16u;
+        qpark.off_od1 = kCandParkCap * 32u;
+    }
+    if (!room_for_all && room < 512u) {  // (the host sizes the slices; never a hang)
+        if (tid == 0) atomicOr(flags, 2u);
+        return;
+    }
+    uint32_t top = 0u;  // wave-uniform: rays on the stack
     auto append = [&](const ShadeOut &so, uint32_t word) {
         PT_PHASE(kPhAppend);
         const uint64_t m1 = __builtin_amdgcn_ballot_w64(so.n_rays >= 1);
         const uint64_t m2 = __builtin_amdgcn_ballot_w64(so.n_rays == 2);
         const uint32_t c1 = (uint32_t)__builtin_popcountll(m1), c2 = (uint32_t)__builtin_popcountll(m2);
         if ((c1 + c2) == 0u) return;  // wave-uniform
-        const uint32_t wbase = tail;
-        tail += c1 + c2;
-        if (so.n_rays >= 1) {
-            const uint32_t slot = wbase + lane_prefix(m1);
-            if (slot < cap_w)
-                store_ray(qout, slot, so.x, so.d0, so.thr0,
-                          pack_word(word_pix(word), word_sample(word), meta_depth(so.meta0), meta_branch(so.meta0)));
-            else
-                overflow = true;
+        const uint32_t wbase = top;
+        if (wbase + c1 + c2 > room) {  // (cannot happen, see above)
+            overflow = true;
+            return;
         }
-        if (so.n_rays == 2) {
-            const uint32_t slot = wbase + c1 + lane_prefix(m2);
-            if (slot < cap_w)
-                store_ray(qout, slot, so.x, so.d1, so.thr1,
-                          pack_word(word_pix(word), word_sample(word), meta_depth(so.meta1), meta_branch(so.meta1)));
-            else
-                overflow = true;
-        }
+        top = rfl(top + c1 + c2);
+        if (so.n_rays >= 1)
+            store_ray(qs, wbase + lane_prefix(m1), so.x, so.d0, so.thr0,
+                      pack_word(word_pix(word), word_sample(word), meta_depth(so.meta0), meta_branch(so.meta0)));
+        if (so.n_rays == 2)
+            store_ray(qs, wbase + c1 + lane_prefix(m2), so.x, so.d1, so.thr1,
+                      pack_word(word_pix(word), word_sample(word), meta_depth(so.meta1), meta_branch(so.meta1)));
     };
     // glass hits of this wave wait in LDS until kCandDeferFlush of them make a dense wave (see k_pass)
     float4 *const dbuf = reinterpret_cast<float4 *>(reinterpret_cast<char *>(dyn_lds) + pass_lds_defer_offset(m)) +
@@ -769,9 +792,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
         }
         append(so, word);
     };
-    // BVH: 64 parked rays (or the rest of a level): the ray again, its walks, shading, appending
-    StreamSlice qin{};
-    uint32_t level = 0;
+    // BVH: 64 parked rays (or the wave's last ones): the ray again (from the parking area), its walks, shading, appending
     uint32_t n_park = 0;  // wave-uniform
     auto walk_batch = [&](uint32_t e, bool valid) {
         ShadeOut so;
@@ -779,16 +800,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
         so.emits = false;
         uint32_t word = 0;
         PT_PHASE(kPhLoad);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the wave's own stores, read back by other lanes)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (valid) {
-            const uint32_t i = p_idx[e];
             PathRay in;
-            if (level == 0u) {
-                const uint32_t pj = (base0 + i) % mb, sj = (base0 + i) / mb;
-                in = primary_ray<PROBE>(F, lds_pix[pj], s0 + sj);
-                word = pack_word(pj, sj, PROBE ? F.depth0 : 0u, 1u);
-            } else {
-                load_ray_slice(qin, i, in.o, in.d, in.thr, word);
-            }
+            load_ray_slice(qpark, e, in.o, in.d, in.thr, word);
             const unsigned long long key = walk_deferred_keys(S, in.o, in.d, wq, p_key[e], walk_keys);
             const uint32_t rank = (uint32_t)key;
             if (rank != 0xffffffffu) {
@@ -809,176 +825,168 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
     PT_PHASE(kPhBarrier);
     __syncthreads();  // accumulators, pixel tables and staged records are in place
     PT_PHASE(kPhOther);
-    for (uint32_t depth = 0; depth < (uint32_t)kMaxDepth && n != 0u; ++depth) {  // (wave-uniform)
-        qin = slice_of((depth & 1u) ? q1 : q0, b * 4u + wv, cap_w);  // level 0 is never stored
-        level = depth;
-        qout = slice_of((depth & 1u) ? q0 : q1, b * 4u + wv, cap_w);
-        tail = 0u;
-        // (Carrying a level's partial chunk over to the next level instead of tracing it half empty - rays keep their own depth
-        // in the bookkeeping word, so a level may mix depths - was built and measured: the partial chunks are 4.8 % of all
-        // chunk trips' lanes (profiles/r03_k_pass_cand_phase_budget.json), but every carried ray lengthens its stream by a
-        // level, and the extra, nearly empty levels at the end of a stream cost what the full chunks saved: cornell 39.3
-        // against 39.6 G bounces/s, mesh.json 21.0 against 22.4; same images.)
-        // (So was handing the level out in chunks of 64 rays that a wave takes from an LDS counter when it is done with one,
-        // instead of a fixed quarter of each 256-ray chunk per wave - the four waves then reach the level's barrier together,
-        // where they wait 3.9 % of their lifetime on cornell and 7.6 % on mesh.json: cornell 39.7 against 40.5, mesh.json 21.6
-        // against 22.6.  And five waves per SIMD: the kernel fits 96 VGPRs with 3 spilled values, but the workgroup's LDS
-        // - 39.5 KB, 18 KB of it the glass-deferral buffers - allows four workgroups per CU; without deferral five waves beat
-        // four, 40.7 against 39.5, but not four with deferral, 40.3; with deferral in 32 KB - 64 entries of 44 bytes - the
-        // kernel spills 8 values in the loop: 37.5.)
-        const uint32_t n_chunks = (n + 63u) >> 6;
-        total += n;
-        vec3 prev_thr = mk(0.0f, 0.0f, 0.0f);  // what the ray started in the trip before still needs from registers
-        uint32_t prev_word = 0;
-        bool prev_valid = false;
-        for (uint32_t it = 0; it <= n_chunks; ++it) {  // uniform trip count; the last trip only finishes chunk n_chunks - 1
-            const uint32_t par = it & 1u;
-            const uint32_t i = (it << 6) | lane;
-            const bool cur_valid = it < n_chunks && i < n;
-            vec3 cur_thr = mk(0.0f, 0.0f, 0.0f);
-            uint32_t word = 0;
-            const uint32_t pending = ring.count;  // entries of chunk it - 1 still queued (< 64)
-            bool ran_batch = false;
-            // (Letting a wave without a ray of this chunk - the partial last chunk of a level - skip the start of the trip was
-            // measured: 38.9 against 39.3 G bounces/s, the extra branch costs more than the skipped work.)
-            if (it < n_chunks) {
-                PT_PHASE(depth == 0u ? kPhPrimary : kPhLoad);
-                PathRay in;
-                in.o = in.d = in.thr = mk(0.0f, 0.0f, 0.0f);
+    uint32_t gen_left = (n0 - base0) < quarter ? (n0 - base0) : quarter;  // primary rays this wave has still to start
+    uint32_t par = 0u;                      // the slots (LDS) of the chunk started in this trip
+    bool pending = false;                   // wave-uniform: the chunk started in the trip before waits to be finished
+    vec3 prev_thr = mk(0.0f, 0.0f, 0.0f);   // what the ray started in the trip before still needs from registers
+    uint32_t prev_word = 0;
+    bool prev_valid = false;
+    for (;;) {  // one trip: start a chunk of up to 64 rays (filters, candidates), finish the chunk started in the trip before
+        const uint32_t phi = 2u * top + 4u * (n_park + n_defer + (pending ? 64u : 0u));
+        const bool may_start = gen_left != 0u && (room_for_all || phi + 256u <= room);
+        uint32_t src = 0u, cnt = 0u;  // 1: pop from the stack, 2: primary rays
+        if (top >= 64u) {
+            src = 1u;
+            cnt = 64u;
+        } else if (may_start) {
+            src = 2u;
+            cnt = gen_left < 64u ? gen_left : 64u;
+        } else if (top != 0u) {
+            src = 1u;
+            cnt = top;
+        }
+        // nothing to start and nothing to finish: what still waits in the wave's side buffers (below), then the end
+        const bool idle = src == 0u && !pending;
+        if (idle && n_defer == 0u && n_park == 0u) break;  // (gen_left is 0: with nothing held phi is 0 and primaries may start)
+        const bool cur_valid = lane < cnt;
+        vec3 cur_thr = mk(0.0f, 0.0f, 0.0f);
+        uint32_t word = 0;
+        const uint32_t pend_entries = ring.count;  // candidate entries of the chunk to finish that are still queued (< 64)
+        bool ran_batch = false;
+        if (src != 0u) {
+            PathRay in;
+            in.o = in.d = in.thr = mk(0.0f, 0.0f, 0.0f);
+            if (src == 2u) {  // render_pixel's rays for (pixel, sample) = (g % mb, s0 + g / mb), g = this wave's next 64 indices
+                PT_PHASE(kPhPrimary);
                 if (cur_valid) {
-                    if (depth == 0u) {  // render_pixel's ray for (pixel i % mb of the stream, sample s0 + i / mb)
-                        const uint32_t pj = gen_pj, sj = gen_sj;
-                        in = PROBE ? primary_ray<PROBE>(F, lds_pix[pj], s0 + sj) : primary_ray_at(F, lds_pix[pj], lds_px[pj], lds_py[pj], s0 + sj);
-                        word = pack_word(pj, sj, PROBE ? F.depth0 : 0u, 1u);
-                    } else {
-                        load_ray_slice(qin, i, in.o, in.d, in.thr, word);
-                    }
+                    const uint32_t pj = gen_pj, sj = gen_sj;
+                    in = PROBE ? primary_ray<PROBE>(F, lds_pix[pj], s0 + sj) : primary_ray_at(F, lds_pix[pj], lds_px[pj], lds_py[pj], s0 + sj);
+                    word = pack_word(pj, sj, PROBE ? F.depth0 : 0u, 1u);
                 }
-                if (depth == 0u) {  // the lane's next ray of level 0
-                    gen_pj += step_r;
-                    gen_sj += step_q;
-                    if (gen_pj >= mb) {
-                        gen_pj -= mb;
-                        gen_sj += 1u;
-                    }
+                gen_pj += step_r;
+                gen_sj += step_q;
+                if (gen_pj >= mb) {
+                    gen_pj -= mb;
+                    gen_sj += 1u;
                 }
-                cur_thr = in.thr;
-                const uint32_t slot = (par << 6) | lane;
-                cand.ray_a[slot] = make_float4(in.o.x, in.o.y, in.o.z, in.d.x);
-                cand.ray_b[slot] = make_float2(in.d.y, in.d.z);
-                float bound;
-                PT_PHASE(kPhSpheres);
-                const unsigned long long key0 = cand_spheres(S, in.o, in.d, &bound);
-                cand.keys[slot] = cur_valid ? key0 : kKeyMiss;
-                const uint32_t before = ring.head;
-                cand_filter_and_drain<STAGED>(S, cand, ring, lane, par, cur_valid, in.o, in.d, bound);
-                ran_batch = ring.head != before;
+                gen_left = rfl(gen_left - cnt);
+            } else {
+                PT_PHASE(kPhLoad);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the wave's own stores, read back by other lanes)
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                top = rfl(top - cnt);
+                if (cur_valid) load_ray_slice(qs, top + lane, in.o, in.d, in.thr, word);
             }
-            if (it > 0u) {
-                PT_PHASE(kPhFinish);
-                // chunk it - 1: its candidates were the oldest entries of the ring; if no full batch ran in this trip (few
-                // candidates, or the flushing trip) run what is queued now
-                if (pending != 0u && !ran_batch) cand_batch<STAGED>(S, cand, ring, lane, ring.count);
-                PT_PHASE(kPhFinish);
-                ShadeOut so;
-                so.n_rays = 0;
-                so.emits = false;
-                so.deferred = false;
-                float hit_t = 0.0f;
-                uint32_t hit_rank = 0xffffffffu;
-                PathRay pr;
-                pr.o = pr.d = pr.thr = mk(0.0f, 0.0f, 0.0f);
-                bool park = false;
-                unsigned long long park_key = 0ull;
-                if (prev_valid) {
-                    const uint32_t slot = ((par ^ 1u) << 6) | lane;
-                    const unsigned long long key = load_key(&cand.keys[slot]);
-                    const uint32_t rank = (uint32_t)key;
-                    if (BVH) {  // (a miss so far may still hit a BVH mesh)
+            total += cnt;
+            cur_thr = in.thr;
+            const uint32_t slot = (par << 6) | lane;
+            cand.ray_a[slot] = make_float4(in.o.x, in.o.y, in.o.z, in.d.x);
+            cand.ray_b[slot] = make_float2(in.d.y, in.d.z);
+            float bound;
+            PT_PHASE(kPhSpheres);
+            const unsigned long long key0 = cand_spheres(S, in.o, in.d, &bound);
+            cand.keys[slot] = cur_valid ? key0 : kKeyMiss;
+            const uint32_t before = ring.head;
+            cand_filter_and_drain<STAGED>(S, cand, ring, lane, par, cur_valid, in.o, in.d, bound);
+            ran_batch = ring.head != before;
+        }
+        if (pending) {
+            PT_PHASE(kPhFinish);
+            // the chunk started in the trip before: its candidates were the oldest entries of the ring; if no full batch ran in
+            // this trip (few candidates, or nothing was started) run what is queued now
+            if (pend_entries != 0u && !ran_batch) cand_batch<STAGED>(S, cand, ring, lane, ring.count);
+            PT_PHASE(kPhFinish);
+            ShadeOut so;
+            so.n_rays = 0;
+            so.emits = false;
+            so.deferred = false;
+            float hit_t = 0.0f;
+            uint32_t hit_rank = 0xffffffffu;
+            PathRay pr;
+            pr.o = pr.d = pr.thr = mk(0.0f, 0.0f, 0.0f);
+            bool park = false;
+            unsigned long long park_key = 0ull;
+            if (prev_valid) {
+                const uint32_t slot = ((par ^ 1u) << 6) | lane;
+                const unsigned long long key = load_key(&cand.keys[slot]);
+                const uint32_t rank = (uint32_t)key;
+                if (BVH) {  // (a miss so far may still hit a BVH mesh)
+                    const float4 ra = cand.ray_a[slot];
+                    const float2 rb = cand.ray_b[slot];
+                    pr.o = mk(ra.x, ra.y, ra.z);
+                    pr.d = mk(ra.w, rb.x, rb.y);
+                    park = bvh_wants(S, pr.o, pr.d, __uint_as_float((uint32_t)(key >> 32)));
+                    park_key = key;
+                }
+                if (rank != 0xffffffffu && !park) {
+                    hit_t = __uint_as_float((uint32_t)(key >> 32));
+                    hit_rank = rank;
+                    if (!BVH) {
                         const float4 ra = cand.ray_a[slot];
                         const float2 rb = cand.ray_b[slot];
                         pr.o = mk(ra.x, ra.y, ra.z);
                         pr.d = mk(ra.w, rb.x, rb.y);
-                        park = bvh_wants(S, pr.o, pr.d, __uint_as_float((uint32_t)(key >> 32)));
-                        park_key = key;
                     }
-                    if (rank != 0xffffffffu && !park) {
-                        hit_t = __uint_as_float((uint32_t)(key >> 32));
-                        hit_rank = rank;
-                        if (!BVH) {
-                            const float4 ra = cand.ray_a[slot];
-                            const float2 rb = cand.ray_b[slot];
-                            pr.o = mk(ra.x, ra.y, ra.z);
-                            pr.d = mk(ra.w, rb.x, rb.y);
-                        }
-                        pr.thr = prev_thr;
-                        pr.pix = lds_pix[word_pix(prev_word)];
-                        pr.meta = pack_meta(s0 + word_sample(prev_word), word_depth(prev_word), word_branch(prev_word));
-                        PT_PHASE(kPhSurface);
-                        const Surface sf = fetch_surface_rank(cand.surf, pr.o, pr.d, hit_t, rank, surf_lds, surf_head);
-                        PT_PHASE_PIN(sf.n.x);
-                        PT_PHASE_PIN(sf.n.y);
-                        PT_PHASE_PIN(sf.n.z);
-                        PT_PHASE_PIN(sf.x.x);
-                        shade_surface<DEFER ? kShadeDeferRefract : kShadeAll>(P, pr, sf, so);
-                        PT_PHASE(kPhEmit);
-                        if (so.emits) add_radiance_lds(lds_acc, m, word_pix(prev_word), so.contrib);
-                    }
-                }
-                append(so, prev_word);
-                if (BVH) {
-                    const uint64_t mw = __builtin_amdgcn_ballot_w64(park);
-                    PT_WSTAT(S, 7, __builtin_popcountll(__builtin_amdgcn_ballot_w64(prev_valid)));  // rays
-                    PT_WSTAT(S, 8, __builtin_popcountll(mw));                                       // parked
-                    PT_WSTAT(S, 9, 1);
-                    if (mw != 0ull) {
-                        if (park) {
-                            const uint32_t e = n_park + lane_prefix(mw);
-                            p_idx[e] = ((it - 1u) << 6) | lane;
-                            p_key[e] = park_key;
-                        }
-                        n_park += (uint32_t)__builtin_popcountll(mw);
-                    }
-                    // 64 parked rays make a batch; the last trip of a level takes what is left (the next level reuses
-                    // the queue slice the rays are read from).  (Dealing the four waves' leftovers out again as batches of
-                    // 64 behind a barrier was tried: fuller batches, but every wave then waits for the slowest scan of the
-                    // level before any leftover is walked - 19.2 against 20.2 G bounces/s on mesh.json.)
-                    while (n_park >= 64u || (it == n_chunks && n_park != 0u)) {  // wave-uniform
-                        const uint32_t cnt = n_park < 64u ? n_park : 64u;
-                        n_park -= cnt;
-                        walk_batch(n_park + lane, lane < cnt);
-                    }
-                }
-                PT_PHASE(kPhDefer);
-                const uint64_t md = DEFER ? __builtin_amdgcn_ballot_w64(so.deferred) : 0ull;
-                if (DEFER && md != 0ull) {
-                    if (so.deferred) {
-                        const uint32_t e = n_defer + lane_prefix(md);
-                        dbuf[e] = make_float4(pr.o.x, pr.o.y, pr.o.z, pr.d.x);
-                        dbuf[kCandDeferCap + e] = make_float4(pr.d.y, pr.d.z, pr.thr.x, pr.thr.y);
-                        dbuf[2u * kCandDeferCap + e] = make_float4(pr.thr.z, __uint_as_float(prev_word), hit_t, __uint_as_float(hit_rank));
-                    }
-                    n_defer += (uint32_t)__builtin_popcountll(md);
-                }
-                if (DEFER && n_defer >= kCandDeferFlush) {  // wave-uniform
-                    const uint32_t cnt = n_defer < 64u ? n_defer : 64u;
-                    n_defer -= cnt;
-                    shade_deferred(n_defer + lane, lane < cnt);
+                    pr.thr = prev_thr;
+                    pr.pix = lds_pix[word_pix(prev_word)];
+                    pr.meta = pack_meta(s0 + word_sample(prev_word), word_depth(prev_word), word_branch(prev_word));
+                    PT_PHASE(kPhSurface);
+                    const Surface sf = fetch_surface_rank(cand.surf, pr.o, pr.d, hit_t, rank, surf_lds, surf_head);
+                    PT_PHASE_PIN(sf.n.x);
+                    PT_PHASE_PIN(sf.n.y);
+                    PT_PHASE_PIN(sf.n.z);
+                    PT_PHASE_PIN(sf.x.x);
+                    shade_surface<DEFER ? kShadeDeferRefract : kShadeAll>(P, pr, sf, so);
+                    PT_PHASE(kPhEmit);
+                    if (so.emits) add_radiance_lds(lds_acc, m, word_pix(prev_word), so.contrib);
                 }
             }
-            PT_PHASE(kPhOther);
-            prev_thr = cur_thr;
-            prev_word = word;
-            prev_valid = cur_valid;
+            append(so, prev_word);
+            if (BVH) {
+                const uint64_t mw = __builtin_amdgcn_ballot_w64(park);
+                PT_WSTAT(S, 7, __builtin_popcountll(__builtin_amdgcn_ballot_w64(prev_valid)));  // rays
+                PT_WSTAT(S, 8, __builtin_popcountll(mw));                                       // parked
+                PT_WSTAT(S, 9, 1);
+                if (mw != 0ull) {
+                    if (park) {  // the whole ray goes to the parking area (its slot in LDS is the next chunk's in two trips)
+                        const uint32_t e = n_park + lane_prefix(mw);
+                        store_ray(qpark, e, pr.o, pr.d, prev_thr, prev_word);
+                        p_key[e] = park_key;
+                    }
+                    n_park = rfl(n_park + (uint32_t)__builtin_popcountll(mw));
+                }
+            }
+            PT_PHASE(kPhDefer);
+            const uint64_t md = DEFER ? __builtin_amdgcn_ballot_w64(so.deferred) : 0ull;
+            if (DEFER && md != 0ull) {
+                if (so.deferred) {
+                    const uint32_t e = n_defer + lane_prefix(md);
+                    dbuf[e] = make_float4(pr.o.x, pr.o.y, pr.o.z, pr.d.x);
+                    dbuf[kCandDeferCap + e] = make_float4(pr.d.y, pr.d.z, pr.thr.x, pr.thr.y);
+                    dbuf[2u * kCandDeferCap + e] = make_float4(pr.thr.z, __uint_as_float(prev_word), hit_t, __uint_as_float(hit_rank));
+                }
+                n_defer = rfl(n_defer + (uint32_t)__builtin_popcountll(md));
+            }
         }
-        if (DEFER && n_defer != 0u) {  // the rest of this wave's glass hits of the level (k_pass: carrying them over loses)
-            shade_deferred(lane, lane < n_defer);
-            n_defer = 0u;
+        // 64 parked rays make a session; an idle wave walks what is left.  (Dealing the four waves' leftovers out again as
+        // batches of 64 behind a barrier was tried in the level-by-level form: fuller batches, but every wave then waits for
+        // the slowest scan of the level before any leftover is walked - 19.2 against 20.2 G bounces/s on mesh.json.)
+        while (BVH && (n_park >= 64u || (idle && n_park != 0u))) {  // wave-uniform
+            const uint32_t c = n_park < 64u ? n_park : 64u;
+            n_park = rfl(n_park - c);
+            walk_batch(n_park + lane, lane < c);
         }
-        // the wave reads back what it has stored itself: its stores are ordered before its loads of the next level
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        n = tail < cap_w ? tail : cap_w;
+        if (DEFER && (n_defer >= kCandDeferFlush || (idle && n_defer != 0u))) {  // wave-uniform
+            const uint32_t c = n_defer < 64u ? n_defer : 64u;
+            n_defer = rfl(n_defer - c);
+            shade_deferred(n_defer + lane, lane < c);
+        }
+        PT_PHASE(kPhOther);
+        prev_thr = cur_thr;
+        prev_word = word;
+        prev_valid = cur_valid;
+        pending = src != 0u;
+        par = rfl(par ^ 1u);
     }
     if (overflow) atomicOr(flags, 1u);
     if (lane == 0u) atomicAdd(reinterpret_cast<unsigned long long *>(s_tail_p), total);
