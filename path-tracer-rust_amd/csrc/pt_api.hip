@@ -289,7 +289,7 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
     // queues (two containers x 4 slots per primary ray x 40 B) of the 288 GB of HBM - fewer, longer launches: cornell 1024x768
     // @4096 spp 32 Mi 35.7, 48 Mi 35.7, 64 Mi 36.2, 96 Mi 36.4 G bounces/s (a launch ends with its slowest streams).
     // k_pass_cand (`stack_form`) keeps a wave's waiting rays on a stack of at most kWaveStackMax slots whatever the pass holds:
-    // its passes are sized by TIME - 384 Mi primary rays, about 0.1 s between two looks at the cancel flag (the reference
+    // its passes are sized by TIME - 512 Mi primary rays, about 0.1 s between two looks at the cancel flag (the reference
     // polls it every 100 ms, mod.rs:947-958) - and its memory is the streams' (K x 4 waves x stack x 40 B: 10.7 GB for 32 Ki
     // streams at most; small passes need less: 4 x pow2(primaries per wave) slots per stream).
     // The default is what the DEVICE can give: 85 % of the free memory (plus what this context's queues hold already),
@@ -305,7 +305,7 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
     uint64_t want = cfg->rays_per_pass ? cfg->rays_per_pass : c->tune.rays_per_pass;
     size_t stack_budget = 0;  // stack_form, default pass size: what the streams' stacks may take
     if (!want) {
-        const uint64_t dflt = stack_form ? (384u << 20) : (96u << 20);
+        const uint64_t dflt = stack_form ? (512u << 20) : (96u << 20);
         want = dflt;
         size_t held = c->hit.bytes();
         for (int w = 0; w < 2; ++w) held += c->q_buf[w].bytes();
@@ -338,7 +338,7 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
         // (candidate scan with walks, mesh.json: 24576 streams 19.8, 26624 20.5, 28672 20.1, 30720 20.3, 32768 19.9 G bounces/s)
         // (k_pass_cand's waves run without levels: a wave's first and last trips - the stack fills, the last rays die - are
         // the only ones that are not full, so its streams are long)
-        const uint64_t per_stream = stack_form ? (uint64_t)(c->tune.per_stream ? c->tune.per_stream : 12288u)
+        const uint64_t per_stream = stack_form ? (uint64_t)(c->tune.per_stream ? c->tune.per_stream : 24576u)
                                                : (c->scene.n_bvh_nodes != 0u ? 4096u : 2048u);
         uint64_t k_target = ((uint64_t)npix * spp_pass + per_stream - 1u) / per_stream;
         if (k_target < 2048u) k_target = 2048u;
@@ -443,16 +443,19 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
     const double cb_every_ms = cfg->progress_ms == PT_PROGRESS_EVERY_PASS ? 0.0 : (cfg->progress_ms ? (double)cfg->progress_ms : 500.0);
     double &cb_last_ms = c->cb_last_ms;  // (set when the call began: pt_ctx_render; a call rendered in parts keeps one clock)
     for (uint32_t p = 0; p < n_pass; ++p) {
-        if (p >= 2) HIP_TRY(hipEventSynchronize(pass_done[p & 1]));  // keep two passes in flight
+        // keep two passes in flight; k_pass_cand's long passes (0.1 s) one - the cancel flag is looked at when a pass ends, and
+        // the few microseconds between two launches are nothing against such a pass
+        if (stack_form && p >= 1) HIP_TRY(hipEventSynchronize(pass_done[(p - 1) & 1]));
+        if (p >= 2) HIP_TRY(hipEventSynchronize(pass_done[p & 1]));
         if (cancel && *cancel) {
             cancelled = true;
             break;
         }
-        if (cb && p >= 2) {
+        if (cb && p >= (stack_form ? 1u : 2u)) {
             const double t_now = now_ms();
             if (t_now - cb_last_ms >= cb_every_ms) {
                 cb_last_ms = t_now;
-                cb(user, (float)(p - 1) / (float)n_pass);
+                cb(user, (float)(stack_form ? p : p - 1u) / (float)n_pass);  // (the passes known to be done)
                 if (cancel && *cancel) {  // raised from inside the callback
                     cancelled = true;
                     break;
@@ -814,6 +817,7 @@ int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uin
     c->scene.n_flat_pairs = (uint32_t)fs.flat_pairs.size();
     c->scene.n_cand_pairs = (uint32_t)fs.cand_pairs.size();
     c->scene.n_other_pairs = fs.n_other_pairs;
+    c->scene.n_flat_exact = fs.n_flat_exact;
     c->cand_ok = fs.cand_ok;
     c->scene.cand_staged = 0u;
     c->scene.surf_staged = 0u;

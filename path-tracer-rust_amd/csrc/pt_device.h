@@ -212,6 +212,7 @@ struct DevScene {
     uint32_t n_bvh_meshes;
     uint32_t n_sph_pairs, n_flat_pairs, n_cand_pairs;
     uint32_t n_other_pairs;         // cand_pairs [0, n_other_pairs) have no filter: candidates for every ray
+    uint32_t n_flat_exact;          // flat_pairs [0, n_flat_exact) have sign_exact set
     uint32_t cand_scan;             // 1: k_pass uses the candidate scan
     uint32_t cand_staged;           // 1: the workgroup holds cand_pairs in LDS
     uint32_t surf_staged;           // 1: ... and surf (set per launch: launch_pass)
@@ -1261,7 +1262,7 @@ struct CandRing {
 // with (A_a - o_a) * sign(d_a) <= 0 (an underflow to zero only rejects more).  For such records the filter keeps a ray only
 // if (plane - origin) * sign(d_a) > 0: about two thirds of the self-candidates go (the origin is on the inner side of the plane,
 // or exactly on it).
-template <int AXIS>
+template <int AXIS, bool EXACT>
 __device__ __forceinline__ void filter_flat(const FlatPairRec &f, vec3 o, vec3 d, vec3 inv, vec3 sgn, float bound, uint64_t valid_m,
                                             uint64_t graze, uint64_t *m0, uint64_t *m1) {
     const float oa = AXIS == 0 ? o.x : (AXIS == 1 ? o.y : o.z), ob = AXIS == 0 ? o.y : (AXIS == 1 ? o.z : o.x),
@@ -1275,7 +1276,7 @@ __device__ __forceinline__ void filter_flat(const FlatPairRec &f, vec3 o, vec3 d
     const f32x2 zc = __builtin_elementwise_fma(splat2(dc), t2, splat2(oc)) - ld2(f.cc);
     const f32x2 lim = splat2(bound) + ld2(f.tpad);
     uint64_t in[2];
-    if (f.sign_exact) {  // wave-uniform
+    if (EXACT) {  // (records with FlatPairRec.sign_exact: a loop of their own, cand_filter_and_drain)
         const f32x2 ts = tv * splat2(sa);  // > 0: the ray moves towards the plane (exact: a product with +-1)
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
@@ -1413,15 +1414,27 @@ __device__ __forceinline__ void cand_filter_and_drain(const DevScene &S, const C
     const uint64_t gz_x = __builtin_amdgcn_ballot_w64(!(f_abs(d.x) >= kGrazing)), gz_y = __builtin_amdgcn_ballot_w64(!(f_abs(d.y) >= kGrazing)),
                    gz_z = __builtin_amdgcn_ballot_w64(!(f_abs(d.z) >= kGrazing));
     const vec3 sgn = mk(__builtin_copysignf(1.0f, d.x), __builtin_copysignf(1.0f, d.y), __builtin_copysignf(1.0f, d.z));
-    for (uint32_t p = 0; p < S.n_flat_pairs; ++p) {
+    for (uint32_t p = 0; p < S.n_flat_exact; ++p) {  // the records with the exact sign rule (the host puts them first)
         const FlatPairRec f = ld_uniform(S.flat_pairs + p);
         uint64_t m0, m1;
         if (f.axis == 0u)
-            filter_flat<0>(f, o, d, inv, sgn, bound, valid_m, gz_x, &m0, &m1);
+            filter_flat<0, true>(f, o, d, inv, sgn, bound, valid_m, gz_x, &m0, &m1);
         else if (f.axis == 1u)
-            filter_flat<1>(f, o, d, inv, sgn, bound, valid_m, gz_y, &m0, &m1);
+            filter_flat<1, true>(f, o, d, inv, sgn, bound, valid_m, gz_y, &m0, &m1);
         else
-            filter_flat<2>(f, o, d, inv, sgn, bound, valid_m, gz_z, &m0, &m1);
+            filter_flat<2, true>(f, o, d, inv, sgn, bound, valid_m, gz_z, &m0, &m1);
+        push2(m0, f.pair[0], m1, f.pair[1]);
+        drain();
+    }
+    for (uint32_t p = S.n_flat_exact; p < S.n_flat_pairs; ++p) {
+        const FlatPairRec f = ld_uniform(S.flat_pairs + p);
+        uint64_t m0, m1;
+        if (f.axis == 0u)
+            filter_flat<0, false>(f, o, d, inv, sgn, bound, valid_m, gz_x, &m0, &m1);
+        else if (f.axis == 1u)
+            filter_flat<1, false>(f, o, d, inv, sgn, bound, valid_m, gz_y, &m0, &m1);
+        else
+            filter_flat<2, false>(f, o, d, inv, sgn, bound, valid_m, gz_z, &m0, &m1);
         push2(m0, f.pair[0], m1, f.pair[1]);
         drain();
     }

@@ -605,6 +605,10 @@ bool flatten_scene(const pt_camera &cam, const pt_object *objs, uint32_t n_objs,
             }
         }
         for (int a = 0; a < 3; ++a) out.flat_pairs.insert(out.flat_pairs.end(), by_axis[a].begin(), by_axis[a].end());
+        // records with the exact sign rule first: the kernels run them in a loop of their own (no branch on the rule per record)
+        out.n_flat_exact = (uint32_t)(std::stable_partition(out.flat_pairs.begin(), out.flat_pairs.end(),
+                                                            [](const FlatPairRec &f) { return f.sign_exact != 0u; }) -
+                                      out.flat_pairs.begin());
         out.n_other_pairs = (uint32_t)out.cand_pairs.size();
         for (FlatPairRec &f : out.flat_pairs)
             for (int hf = 0; hf < 2; ++hf)

@@ -28,6 +28,7 @@ struct FlatScene {
     std::vector<uint32_t> tri_rank;  // rank of triangle k (the inverse of rank_id over the triangles)
     std::vector<BvhMeshRec> bvh_meshes;  // the meshes that have a BVH, in visiting order (last object first)
     uint32_t n_other_pairs = 0;
+    uint32_t n_flat_exact = 0;  // flat_pairs [0, n_flat_exact) have sign_exact set (they come first)
     bool cand_ok = false;  // the scene can use the candidate scan (the records of its meshes without a BVH are numbered in
                            // 9 bits; meshes with a BVH are walked: k_pass_cand<.., BVH>)
     uint32_t bvh_stack = 0;      // traversal-stack entries the deepest tree needs (<= kBvhStack)
