@@ -424,7 +424,6 @@ __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, R
     // makes it a division per lookup, and it is needed once per bounce
     uint32_t *lds_pix = s_tail_p + 4;
     for (uint32_t j = tid; j < mb; j += kBlock) lds_pix[j] = global_pixel(F, stream_pixel(F.n_streams, b, j));
-    const size_t base = (size_t)b * cap;
     ShadeParams P;
     P.idx_begin = F.idx_begin;
     P.npix = F.npix;
@@ -578,20 +577,19 @@ __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, R
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_pass with the candidate scan (pt_device.h: "Candidate scan"): the same walk of a stream, but a ray is FINISHED one
-// chunk after it was started.  Trip `it` of the chunk loop loads (or generates) the rays of chunk `it`, puts origin and
-// direction into the chunk's slots in LDS, tests the spheres, runs the filters and queues the candidates; full batches of
-// 64 candidates are run as the ring fills; then every candidate of chunk `it - 1` has been through a batch (they were
-// the oldest entries of the ring), so the rays of chunk `it - 1` take their hit from their key, are shaded and appended.
-// One trip beyond the last chunk flushes the ring.  Streams, levels, accumulators and the final flush are k_pass's;
-// glass hits are shaded in place (the deferral buffers' LDS is what the ray slots use here).
+// k_pass with the candidate scan (pt_device.h: "Candidate scan") and WITHOUT LEVELS: a ray is FINISHED one chunk after it was
+// started, and the rays that wait for their next bounce live on a stack of the wave (see "THE WAVE'S RAY STACK" in the body).
+// A trip of a wave's loop starts a chunk of 64 rays - popped from the stack, or new primary rays when fewer than 64 wait - puts
+// origin and direction into the chunk's slots in LDS, tests the spheres, runs the filters and queues the candidates; full
+// batches of 64 candidates are run as the ring fills; then every candidate of the chunk started in the trip BEFORE has been
+// through a batch (they were the oldest entries of the ring), so those rays take their hit from their key, are shaded and
+// their continuations pushed.  Accumulators and the final flush are k_pass's; glass hits are deferred per wave as in k_pass.
 // BVH = true (scenes with BVH meshes): when a ray is finished - its key holds the best of the spheres and of the candidate
-// records - bvh_wants decides whether it has to walk a BVH mesh; such a ray is not shaded but PARKED per wave in LDS
-// (ray index + key, 12 B; the ray stays in the queue, a primary ray is generated again), and 64 parked rays at a time are
-// walked (bvh_closest_queue: the wave's pending box tests as one queue), the closest triangle folded into the key by rank,
-// shaded and appended.
+// records - bvh_wants decides whether it has to walk a BVH mesh; such a ray is not shaded but PARKED per wave (the ray in the
+// wave's parking area in global memory, its key in LDS), and 64 parked rays at a time are walked (bvh_closest_queue: the
+// wave's pending box tests as one queue), the closest triangle folded into the key by rank, shaded and pushed.
 // LDS of that form, between the per-wave candidate areas and the staged records:
-//   [per wave: walk queue (pass_cand_queue_bytes)][per wave: park u32 idx x 128, u64 key x 128][per wave: u64 key x 64]
+//   [per wave: walk queue (pass_cand_queue_bytes)][per wave: u64 key x 128 of the parked rays][per wave: u64 key x 64]
 constexpr uint32_t kCandParkCap = kWaveParkCap;  // 63 left over + 64 new at most
 // per wave: the walk queue (header + 8-byte entries: box tests from one end, leaves from the other), which is also where
 // the depth-first stacks (DevScene.bvh_stack entries x 64 lanes x u16, or u32 when a tree has 32 768 nodes or leaves) and
@@ -602,7 +600,7 @@ __host__ __device__ inline size_t pass_cand_queue_bytes(const DevScene &S) {
     return kWalkQueueHeader + (((again > kWalkQueueBytes ? again : kWalkQueueBytes) + 15) & ~(size_t)15);
 }
 __host__ __device__ inline size_t pass_cand_queues_bytes(const DevScene &S) { return (size_t)(kBlock / 64u) * pass_cand_queue_bytes(S); }
-constexpr size_t kCandParkBytes = kCandParkCap * 12u;                  // per wave
+constexpr size_t kCandParkBytes = kCandParkCap * 8u;                   // per wave: the parked rays' keys
 constexpr size_t kCandWalkKeyBytes = 64u * 8u;                         // per wave: the walkers' keys
 __host__ __device__ inline size_t pass_cand_bvh_bytes(const DevScene &S) {
     return pass_cand_queues_bytes(S) + (size_t)(kBlock / 64u) * (kCandParkBytes + kCandWalkKeyBytes);
@@ -638,13 +636,12 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
         lds_px[j] = pix % F.width;
         lds_py[j] = F.height - 1u - pix / F.width;
     }
-    // ray g of level 0 is (pixel g % mb of the stream, sample g / mb); a lane's rays are 256 apart, so its (pixel, sample)
-    // advance by (256 % mb, 256 / mb) with a carry - no division per trip
-    // THE WAVES OF A WORKGROUP DO NOT WAIT FOR EACH OTHER: every wave walks a quarter of the stream on its own - a contiguous
-    // quarter of the stream's level-0 rays, and from then on its own quarter of the stream's queue slice (cap / 4 slots: four
-    // times its primaries, the host leaves room for the rounding) - so the level boundaries need no workgroup barrier (where
-    // the four waves used to wait 3.5 % of their lifetime on cornell and 9 % on mesh.json, whose walks differ from wave to
-    // wave), and the slice's tail is a scalar register of the wave instead of an LDS counter behind an atomic.
+    // THE WAVES OF A WORKGROUP DO NOT WAIT FOR EACH OTHER: every wave traces a contiguous quarter of the stream's primary rays
+    // on its own, its waiting rays on a stack of its own (below) - no workgroup barrier between the first one (LDS tables in
+    // place) and the last (accumulators complete).  The workgroup shares the stream's pixel accumulators (LDS atomics) and
+    // the staged scene records.
+    // Primary ray g of the stream is (pixel g % mb, sample g / mb); a lane's primaries are 64 apart, so its (pixel, sample)
+    // advance by (64 % mb, 64 / mb) with a carry - no division per trip.
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const uint32_t cap_w = cap >> 2;
     const uint32_t n0 = mb * s_here;                  // level-0 rays of the stream
@@ -688,14 +685,12 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
     }
     // BVH: the waves' walk queues, then this wave's parking area and walk keys
     char *const walk_lds = (reinterpret_cast<char *>(dyn_lds) + pass_lds_cand_offset(m, DEFER) + pass_lds_cand_bytes());
-    uint32_t *p_idx = nullptr;
     unsigned long long *p_key = nullptr;
     unsigned long long *walk_keys = nullptr;
     WalkQueue wq{};
     if (BVH) {
         char *wb = walk_lds + pass_cand_queues_bytes(S) + (size_t)(tid >> 6) * (kCandParkBytes + kCandWalkKeyBytes);
         p_key = reinterpret_cast<unsigned long long *>(wb);
-        p_idx = reinterpret_cast<uint32_t *>(wb + kCandParkCap * 8u);
         walk_keys = reinterpret_cast<unsigned long long *>(wb + kCandParkBytes);
         char *qb = walk_lds + (size_t)(tid >> 6) * pass_cand_queue_bytes(S);
         wq.redo = reinterpret_cast<uint32_t *>(qb);
@@ -707,8 +702,13 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
     P.idx_begin = F.idx_begin;
     P.npix = F.npix;
     P.n_streams = F.n_streams;
-    P.seed_lo = F.seed_lo;
-    P.seed_hi = F.seed_hi;
+    {  // the key as two scalars of their own: left inside FrameParams' sixteen-register tuple, every draw of the loop
+       // fetched the whole tuple back from the VGPR lanes the register allocator had parked it in (16 v_readlane per site)
+        uint32_t k_lo = F.seed_lo, k_hi = F.seed_hi;
+        asm volatile("" : "+s"(k_lo), "+s"(k_hi));
+        P.seed_lo = k_lo;
+        P.seed_hi = k_hi;
+    }
     P.debug = F.debug;
     P.s0 = s0;
     P.chunk_pixels = F.chunk_pixels;
@@ -845,7 +845,14 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
             src = 1u;
             cnt = top;
         }
+        src = rfl(src);
+        cnt = rfl(cnt);
         // nothing to start and nothing to finish: what still waits in the wave's side buffers (below), then the end
+        // (A wave's last rays - its primaries used up, fewer than 64 waiting - take some 30 trips of ever fewer lanes.  Leaving
+        // them to ONE wave of the workgroup - waves 1-3 stop at that point, wave 0 moves their rays onto its own stack and
+        // traces the workgroup's last rays alone, a few full trips and one fading tail instead of four - was built and
+        // measured: the three idle wave slots cost more than the partial trips, cornell 43.7 against 45.5 G bounces/s,
+        // mesh.json 22.5 against 26.6.)
         const bool idle = src == 0u && !pending;
         if (idle && n_defer == 0u && n_park == 0u) break;  // (gen_left is 0: with nothing held phi is 0 and primaries may start)
         const bool cur_valid = lane < cnt;
@@ -1051,7 +1058,6 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_bvh(DevScene S, FrameParams 
         leaves.keys = reinterpret_cast<unsigned long long *>(lbase);
         leaves.list = reinterpret_cast<uint32_t *>(lbase + 64u * 8u);
     }
-    const size_t base = (size_t)b * cap;
     ShadeParams P;
     P.idx_begin = F.idx_begin;
     P.npix = F.npix;
