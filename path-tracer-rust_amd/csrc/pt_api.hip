@@ -328,6 +328,15 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
         if (spp_pass == 0) spp_pass = 1;
         if (spp_pass > cfg->spp) spp_pass = cfg->spp;
         if (spp_pass > kMaxPassSpp) spp_pass = kMaxPassSpp;  // sample-in-pass field of the stream bookkeeping word
+        if (stack_form && spp_pass < cfg->spp) {
+            // passes of equal length (4096 samples in passes of 682 at most would end with one of 4 samples: short streams,
+            // a launch that cannot fill the chip); a pass may be up to a twentieth longer than asked for that - k_pass_cand's
+            // memory does not grow with the pass
+            const uint32_t stretch = spp_pass + spp_pass / 20u;
+            const uint32_t n_eq = (cfg->spp + stretch - 1u) / stretch;
+            const uint32_t eq = (cfg->spp + n_eq - 1u) / n_eq;
+            if (eq <= kMaxPassSpp) spp_pass = eq;
+        }
         // Streams: many more than the 2048 workgroups the chip holds at once, so that the dispatcher keeps every CU busy
         // until a launch ends, but each still a few launches' worth of work for its workgroup - about 2048 primary rays
         // per stream and pass (measured on cornell 1024x768: 2048 streams 22.0, 8192 24.3, 16384 24.7, 65536 23.2 G
@@ -346,6 +355,11 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
         m = (uint32_t)((npix + k_target - 1) / k_target);
         if (m == 0) m = 1;
         if (m > kMaxStreamPixels) m = kMaxStreamPixels;
+        // k_pass_cand: a stream's accumulators and pixel tables (36 B per pixel) share the workgroup's 40 KB of LDS with the
+        // glass-deferral buffers and the staged records, which fit up to 72 pixels on the bench scene: frames of few samples
+        // get more, shorter streams rather than a kernel without them (1024x768 @128: 12 288 streams of 64 pixels, not 4 096
+        // of 192)
+        if (stack_form && !c->tune.streams && m > 64u) m = 64u;
         // A launch runs its workgroups in rounds of as many as the chip holds (four per CU); a stream's work grows with its m
         // pixels, so a launch takes about ceil(K / resident) x m: among the m within -15 % / +20 % of the tuned size take the
         // one for which that is smallest (cornell 1024x768: m = 21 -> 24, 37 450 streams in 36.6 rounds -> 32 768 in 32.0,
@@ -355,7 +369,7 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
             const uint64_t resident = (uint64_t)c->n_cus * 4u;
             uint32_t best_m = m;
             uint64_t best_cost = ~0ull;
-            for (uint32_t mm = m - m * 15u / 100u; mm <= m + m / 5u && mm <= kMaxStreamPixels; ++mm) {
+            for (uint32_t mm = m - m * 15u / 100u; mm <= m + m / 5u && mm <= (stack_form ? 72u : kMaxStreamPixels); ++mm) {
                 const uint64_t kk = (npix + mm - 1u) / mm;
                 const uint64_t cost = ((kk + resident - 1u) / resident) * mm;
                 if (cost < best_cost || (cost == best_cost && (mm > m ? mm - m : m - mm) < (best_m > m ? best_m - m : m - best_m))) {

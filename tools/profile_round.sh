@@ -14,8 +14,8 @@ if [ -f scratch/libptrace_phase.so ]; then
   PT_LIB=scratch/libptrace_phase.so python3 tools/phase_budget.py mesh 128 gpurun_out/${T}_k_pass_cand_bvh_phase_budget.json > gpurun_out/${T}_phase_mesh.txt 2>&1
 fi
 if [ -x tools/rounding_search ]; then ./tools/rounding_search > gpurun_out/${T}_rounding_search.json; fi
-$R/tools/pmc_run.sh ${T}a --spp 128
-$R/tools/pmc_run.sh ${T}m --scene mesh --spp 64
+$R/tools/pmc_run.sh ${T}a --spp 683
+$R/tools/pmc_run.sh ${T}m --scene mesh --spp 512
 $R/tools/pmc_run.sh ${T}g --backend megakernel --spp 128
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/stats_${T}a -- python3 $R/bench.py --no-cpu-baseline --no-variants > $R/gpurun_out/stats_${T}a.log 2>&1
