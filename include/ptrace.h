@@ -105,7 +105,8 @@ typedef struct pt_config {
     uint64_t seed;     /* key of the counter-based RNG that stands in for rand::random (mod.rs:53) */
     uint32_t idx_begin; /* framebuffer-index band [idx_begin, idx_end) to render; 0,0 = whole frame */
     uint32_t idx_end;
-    uint32_t rays_per_pass; /* wavefront: primary rays generated per pass; 0 = library default */
+    uint32_t rays_per_pass; /* wavefront: primary rays generated per pass; 0 = library default (512 Mi: about 0.1 s per
+                             * pass on the bench scene - cancel and progress are looked at between passes) */
     uint32_t flags;
     /* Interleaved partition of the band for load balance across ranks (the cost of a pixel varies over the
      * image: contiguous eighths of cornell.json differ by up to 1.31x).  The band is cut into chunks of
@@ -188,9 +189,12 @@ int pt_device_download(int device, void *dst_host, const void *src_device, size_
 int pt_bvh_refs_fit(uint64_t n_bvh_nodes, uint64_t n_pair_records);
 
 /* Device memory the wavefront backend may take for its ray queues in this context (bytes; 0 = the default: 85 % of what
- * the device reports free, divided among the contexts one call creates on it, at most 36 GB).  The queues hold
- * rays_per_pass primary rays at 352 B each; a pass that does not fit is halved until it does (a failed allocation does the
- * same), which changes how the samples are batched and nothing in the image. */
+ * the device reports free, divided among the contexts one call creates on it).  The default kernel (k_pass_cand) keeps
+ * each wave's waiting rays on a stack of at most 2048 slots: K streams x 4 waves x 80 KB, whatever the pass holds (5.4 GB
+ * for the 16 Ki streams of a 1024x768 pass; small passes need less); the level-by-level forms (PT_FLAG_SEPARATE_KERNELS,
+ * PT_FLAG_NO_BVH, PT_CAND_SCAN=0) hold rays_per_pass primary rays at 352 B each, 36 GB at their default.  A pass that does
+ * not fit is halved until it does (a failed allocation does the same), which changes how the samples are batched and
+ * nothing in the image. */
 int pt_ctx_set_memory_budget(pt_ctx *ctx, size_t bytes);
 
 /* Enable HIP-event timing of every launch of the dominant kernel (fills pt_stats.ms_intersect). */
