@@ -17,7 +17,10 @@ The JSON line also carries
                 (k_pass_cand): its algorithmic traffic is the ray queue - every ray of depth >= 1 is written once and
                 read once, 40 B each way (origin, direction, throughput, bookkeeping word); primary rays are made in
                 registers and hit records never leave them (k_pass_bvh, scenes with a BVH: the primaries go through the
-                queue too).  With PT_FLAG_SEPARATE_KERNELS the figure is k_intersect's (24 B ray in + 8 B hit out).
+                queue too).  k_pass_cand keeps that queue as one small stack per wave, which stays in L2: `traffic` -
+                the HBM bytes the PMC counters saw - is then far BELOW the algorithmic bytes (9.4 against 70.8 B per
+                bounce on the bench scene).  With PT_FLAG_SEPARATE_KERNELS the figure is k_intersect's (24 B ray in +
+                8 B hit out).
                 "binds": false - HBM is not what limits these kernels;
   valu_roofline what does: VALU instruction issue, priced with the per-class cycle costs measured on the box
                 (tools/valu_issue_bench.hip -> profiles/r02_valu_issue_costs.json), the kernel's dynamic instruction count

@@ -79,6 +79,10 @@ struct Tuning {
     uint64_t streams = 0;      // PT_STREAMS: ray streams per pass (0 = derived from the frame)
     uint32_t per_stream = 0;   // PT_PER_STREAM: primary rays per stream and pass that k_pass_cand's stream count aims at (0 = default)
     uint64_t rays_per_pass = 0;  // PT_RAYS_PER_PASS: the default of pt_config.rays_per_pass (probes; 0 = the library's)
+    bool nodes_lds = true;       // PT_NODES_LDS=0: k_pass_cand with walks reads the BVH nodes from global memory even when they
+                                 // would fit its LDS (A/B)
+    uint32_t wave_stack = 0;     // PT_WAVE_STACK=n: k_pass_cand's stacks hold n slots (a power of two, 512 <= n < kWaveStackMax)
+                                 // instead of kWaveStackMax - the waves then have to hold their primaries back (tests)
     uint32_t debug = 0;
 };
 static Tuning read_tuning() {
@@ -98,6 +102,11 @@ static Tuning read_tuning() {
     t.streams = st > 0 ? (uint64_t)st : 0;
     t.per_stream = (uint32_t)num("PT_PER_STREAM", 0);
     t.rays_per_pass = (uint64_t)num("PT_RAYS_PER_PASS", 0);
+    t.nodes_lds = num("PT_NODES_LDS", 1) != 0;
+    {
+        const long long ws = num("PT_WAVE_STACK", 0);
+        if (ws >= 512 && ws < (long long)kWaveStackMax && (ws & (ws - 1)) == 0) t.wave_stack = (uint32_t)ws;
+    }
 #ifdef PT_ALLOW_DEBUG
     t.debug = (uint32_t)num("PT_DEBUG", 0);
 #endif
@@ -388,9 +397,10 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
         if (stack_form) {
             const uint64_t need_w = (uint64_t)m * spp_pass + 8u;
             uint64_t cap_w = 128u;
-            while (cap_w < need_w && cap_w < kWaveStackMax) cap_w *= 2u;
+            const uint64_t stack_max = c->tune.wave_stack ? c->tune.wave_stack : kWaveStackMax;
+            while (cap_w < need_w && cap_w < stack_max) cap_w *= 2u;
             cap64 = 4u * cap_w;
-            if (stack_budget && queue_bytes(K, (uint32_t)cap64) + (stack_park ? queue_bytes(K, 4u * kWaveParkCap) : 0u) > stack_budget &&
+            if (stack_budget && queue_bytes(K, (uint32_t)cap64) + (stack_park ? (size_t)K * 4u * kWaveParkBytes : 0u) > stack_budget &&
                 spp_pass > 1u) {  // the default pass does not fit the budget: smaller passes have fewer streams or smaller stacks
                 want = (uint64_t)npix * (spp_pass / 2u);
                 continue;
@@ -410,7 +420,7 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
         int rc = PT_OK;
         rc = c->q_buf[0].ensure(queue_bytes(K, cap), true);
         if (!rc && !stack_form) rc = c->q_buf[1].ensure(queue_bytes(K, cap), true);
-        if (!rc && stack_park) rc = c->q_buf[1].ensure(queue_bytes(K, 4u * kWaveParkCap), true);
+        if (!rc && stack_park) rc = c->q_buf[1].ensure((size_t)K * 4u * kWaveParkBytes, true);
         // scenes without BVH meshes run a pass as one launch (k_pass), BVH scenes as k_pass_bvh unless their nodes are staged
         // in LDS; PT_FLAG_SEPARATE_KERNELS / PT_PASS_KERNEL=0 / PT_PASS_BVH=0 keep the three-kernel form (A/B, profiling).
         // Only that form needs the hit records: k_pass keeps hits in registers.
@@ -832,6 +842,7 @@ int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uin
     c->scene.n_cand_pairs = (uint32_t)fs.cand_pairs.size();
     c->scene.n_other_pairs = fs.n_other_pairs;
     c->scene.n_flat_exact = fs.n_flat_exact;
+    c->scene.nodes_in_lds_ok = c->tune.nodes_lds ? 1u : 0u;
     c->cand_ok = fs.cand_ok;
     c->scene.cand_staged = 0u;
     c->scene.surf_staged = 0u;

@@ -192,7 +192,9 @@ struct DevScene {
     uint32_t n_objs;
     uint32_t n_tris;
     uint32_t n_bvh_nodes;  // 0: no mesh of the scene has a BVH (or BVH use is switched off for this frame)
-    uint32_t bvh_in_lds;   // bit 0: nodes are staged in LDS; bit 1: child references fit 16 bits (u16 traversal stacks)
+    uint32_t bvh_in_lds;   // bit 0: nodes are staged in LDS; bit 1: child references fit 16 bits (u16 traversal stacks);
+                           // bit 2 (set by launch_pass for k_pass_cand with walks): that kernel stages the nodes in LDS and its
+                           // walk queues hold kWalkQueueBytesStaged
     uint32_t bvh_pair_base;  // first TriPairRec that is a BVH leaf (leaf references on a u16 stack are relative to it)
     uint32_t bvh_stack;      // traversal-stack entries the deepest tree of the scene needs (<= kBvhStack): k_pass_cand sizes its LDS by it
     uint32_t leaf_quorum;    // BVH walk: lanes on a leaf that send the wave to the triangle code (see bvh_closest)
@@ -213,6 +215,7 @@ struct DevScene {
     uint32_t n_sph_pairs, n_flat_pairs, n_cand_pairs;
     uint32_t n_other_pairs;         // cand_pairs [0, n_other_pairs) have no filter: candidates for every ray
     uint32_t n_flat_exact;          // flat_pairs [0, n_flat_exact) have sign_exact set
+    uint32_t nodes_in_lds_ok;       // k_pass_cand with walks may stage the BVH nodes in LDS when they fit (PT_NODES_LDS=0: never)
     uint32_t cand_scan;             // 1: k_pass uses the candidate scan
     uint32_t cand_staged;           // 1: the workgroup holds cand_pairs in LDS
     uint32_t surf_staged;           // 1: ... and surf (set per launch: launch_pass)
@@ -587,6 +590,25 @@ __device__ __forceinline__ void hit_boxes(const BvhNode &n, f32x2 ivx, f32x2 ivy
     *h1 = tin[1] <= lim[1] && tin[1] <= bound;
     *t_in = tin;
 }
+// the same with the verdicts as WAVE MASKS (every lane of the wave calls it): ballots of the single comparisons combined by
+// scalar and - a ballot of a boolean that is itself a combination of comparisons costs a v_cndmask and a v_cmp on top
+__device__ __forceinline__ void hit_boxes_masks(const BvhNode &n, f32x2 ivx, f32x2 ivy, f32x2 ivz, f32x2 oix, f32x2 oiy,
+                                                f32x2 oiz, float bound, uint64_t *m0, uint64_t *m1, f32x2 *t_in) {
+    const f32x2 ax = __builtin_elementwise_fma(ld2(n.lox), ivx, -oix), bx = __builtin_elementwise_fma(ld2(n.hix), ivx, -oix);
+    const f32x2 ay = __builtin_elementwise_fma(ld2(n.loy), ivy, -oiy), by = __builtin_elementwise_fma(ld2(n.hiy), ivy, -oiy);
+    const f32x2 az = __builtin_elementwise_fma(ld2(n.loz), ivz, -oiz), bz = __builtin_elementwise_fma(ld2(n.hiz), ivz, -oiz);
+    const f32x2 zero = splat2(0.0f);
+    const f32x2 tin = __builtin_elementwise_max(
+        __builtin_elementwise_max(__builtin_elementwise_min(ax, bx), __builtin_elementwise_min(ay, by)),
+        __builtin_elementwise_max(__builtin_elementwise_min(az, bz), zero));
+    const f32x2 tout = __builtin_elementwise_min(
+        __builtin_elementwise_min(__builtin_elementwise_max(ax, bx), __builtin_elementwise_max(ay, by)),
+        __builtin_elementwise_max(az, bz));
+    const f32x2 lim = tout * splat2(1.0000005f);
+    *m0 = __builtin_amdgcn_ballot_w64(tin[0] <= lim[0]) & __builtin_amdgcn_ballot_w64(tin[0] <= bound);
+    *m1 = __builtin_amdgcn_ballot_w64(tin[1] <= lim[1]) & __builtin_amdgcn_ballot_w64(tin[1] <= bound);
+    *t_in = tin;
+}
 
 // Traversal-stack entry codecs.  With the nodes staged in LDS the scene has < 2^15 nodes and BVH leaves, so a
 // child reference fits 16 bits (halves the LDS the stacks take, which is what bounds occupancy here).
@@ -887,9 +909,9 @@ __device__ __forceinline__ void bvh_closest_queue(const DevScene &S, NodePtr nod
             // 19.3 G bounces/s on mesh.json; so do leaf batches started at 32 waiting leaves: 18.7)
             const uint32_t c = q_count < n_act ? q_count : n_act;
             q_count -= c;
-            bool valid = my < c;
+            const bool has = my < c;
             uint2 e = make_uint2(lane, 0u);
-            if (valid) e = Q.ent[q_count + my];
+            if (has) e = Q.ent[q_count + my];
             const uint32_t owner = e.x & 63u;
             const int sel = (int)(owner << 2);
             const float r_ivx = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(inv.x)));
@@ -899,40 +921,46 @@ __device__ __forceinline__ void bvh_closest_queue(const DevScene &S, NodePtr nod
             const float r_oiy = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(oi.y)));
             const float r_oiz = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(oi.z)));
             const float bound = __uint_as_float((uint32_t)(load_key(&keys[owner]) >> 32) + 1u);
-            valid = valid && !(__uint_as_float(e.y) > bound);  // the owner has found something nearer since the item was pushed
-            PT_WSTAT(S, 1, 1);                                                               // batches of box tests
-            PT_WSTAT(S, 2, c);                                                               // items
-            PT_WSTAT(S, 3, __builtin_popcountll(__builtin_amdgcn_ballot_w64(valid)));        // ... still worth testing
-            bool h0 = false, h1 = false, first0 = true;
-            int32_t c0 = 0, c1 = 0;
-            f32x2 tin = splat2(0.0f);
-            if (valid) {
-                const BvhNode n = nodes[e.x >> 6];
-                hit_boxes(n, splat2(r_ivx), splat2(r_ivy), splat2(r_ivz), splat2(r_oix), splat2(r_oiy), splat2(r_oiz), bound, &h0, &h1,
-                          &tin);
-                first0 = tin[0] <= tin[1];
-                c0 = n.c[0];
-                c1 = n.c[1];
-            }
+            // the item is still worth testing unless its owner has found something nearer since it was pushed
+            const uint64_t m_valid = __builtin_amdgcn_ballot_w64(has) & ~__builtin_amdgcn_ballot_w64(__uint_as_float(e.y) > bound);
+            PT_WSTAT(S, 1, 1);                                   // batches of box tests
+            PT_WSTAT(S, 2, c);                                   // items
+            PT_WSTAT(S, 3, __builtin_popcountll(m_valid));       // ... still worth testing
+            // Every lane tests a node - the ones without an item node 0 with their own ray, a harmless read - and the verdicts
+            // are wave masks that scalar and / or combine: a divergent branch around the test and ballots of combined
+            // booleans cost four v_cndmask / v_cmp pairs per batch.
+            uint64_t m_h0, m_h1;
+            f32x2 tin;
+            const BvhNode n = nodes[e.x >> 6];
+            hit_boxes_masks(n, splat2(r_ivx), splat2(r_ivy), splat2(r_ivz), splat2(r_oix), splat2(r_oiy), splat2(r_oiz), bound, &m_h0, &m_h1,
+                            &tin);
+            m_h0 &= m_valid;
+            m_h1 &= m_valid;
+            const bool first0 = tin[0] <= tin[1];
+            const int32_t c0 = n.c[0], c1 = n.c[1];
             // children that are leaves -> leaf list; children that are nodes -> queue, the nearer of two on top
             // (sending the farther of two hit children, when it is a leaf, through the queue once more - to be dropped if
             // the nearer subtree has found something in front of it by then - does not pay: the nearer leaf has rarely
             // been tested when the item comes up again; 5.12 instead of 5.18 leaves per walk, 20.3 instead of 18.2 batches)
-            const bool l0 = h0 && c0 < 0, l1 = h1 && c1 < 0, n0 = h0 && c0 >= 0, n1 = h1 && c1 >= 0;
-            const bool two = n0 && n1, one = n0 || n1;
-            const uint64_t m_l0 = __builtin_amdgcn_ballot_w64(l0), m_l1 = __builtin_amdgcn_ballot_w64(l1);
-            const uint64_t m_far = __builtin_amdgcn_ballot_w64(two), m_near = __builtin_amdgcn_ballot_w64(one);
+            const uint64_t m_neg0 = __builtin_amdgcn_ballot_w64(c0 < 0), m_neg1 = __builtin_amdgcn_ballot_w64(c1 < 0);
+            const uint64_t m_l0 = m_h0 & m_neg0, m_l1 = m_h1 & m_neg1, m_n0 = m_h0 & ~m_neg0, m_n1 = m_h1 & ~m_neg1;
+            const uint64_t m_far = m_n0 & m_n1, m_near = m_n0 | m_n1;
             const uint32_t add_q = count(m_far) + count(m_near), add_l = count(m_l0) + count(m_l1);
             if (q_count + n_leaf + add_q + add_l > Q.cap) {  // wave-uniform: no room - these rays are walked again afterwards
-                if (h0 || h1) atomicOr(&Q.redo[owner >> 5], 1u << (owner & 31u));
+                if (__builtin_amdgcn_inverse_ballot_w64(m_h0 | m_h1)) atomicOr(&Q.redo[owner >> 5], 1u << (owner & 31u));
                 PT_WSTAT(S, 11, 1);
             } else {
-                const bool near0 = two ? first0 : n0;  // which child is the (nearer) node pushed last
-                if (two) Q.ent[q_count + prefix(m_far)] = make_uint2(owner | ((uint32_t)(near0 ? c1 : c0) << 6), __float_as_uint(near0 ? tin[1] : tin[0]));
-                if (one) Q.ent[q_count + count(m_far) + prefix(m_near)] = make_uint2(owner | ((uint32_t)(near0 ? c0 : c1) << 6), __float_as_uint(near0 ? tin[0] : tin[1]));
+                const bool n0 = __builtin_amdgcn_inverse_ballot_w64(m_n0);
+                const bool near0 = __builtin_amdgcn_inverse_ballot_w64(m_far) ? first0 : n0;  // which child is the (nearer) node pushed last
+                if (__builtin_amdgcn_inverse_ballot_w64(m_far))
+                    Q.ent[q_count + prefix(m_far)] = make_uint2(owner | ((uint32_t)(near0 ? c1 : c0) << 6), __float_as_uint(near0 ? tin[1] : tin[0]));
+                if (__builtin_amdgcn_inverse_ballot_w64(m_near))
+                    Q.ent[q_count + count(m_far) + prefix(m_near)] = make_uint2(owner | ((uint32_t)(near0 ? c0 : c1) << 6), __float_as_uint(near0 ? tin[0] : tin[1]));
                 q_count += add_q;
-                if (l0) Q.ent[Q.cap - 1u - (n_leaf + prefix(m_l0))] = make_uint2(owner | ((uint32_t)~c0 << 6), __float_as_uint(tin[0]));
-                if (l1) Q.ent[Q.cap - 1u - (n_leaf + count(m_l0) + prefix(m_l1))] = make_uint2(owner | ((uint32_t)~c1 << 6), __float_as_uint(tin[1]));
+                if (__builtin_amdgcn_inverse_ballot_w64(m_l0))
+                    Q.ent[Q.cap - 1u - (n_leaf + prefix(m_l0))] = make_uint2(owner | ((uint32_t)~c0 << 6), __float_as_uint(tin[0]));
+                if (__builtin_amdgcn_inverse_ballot_w64(m_l1))
+                    Q.ent[Q.cap - 1u - (n_leaf + count(m_l0) + prefix(m_l1))] = make_uint2(owner | ((uint32_t)~c1 << 6), __float_as_uint(tin[1]));
                 n_leaf += add_l;
             }
         }
@@ -1530,7 +1558,8 @@ __device__ __forceinline__ bool bvh_wants(const DevScene &S, vec3 o, vec3 d, flo
 // 2. the walks of a parked ray: every BVH mesh in visiting order, exact gate first; the closest triangle of a mesh (the
 //    first in list order among equals: bvh_closest_postponed) enters the key with its rank - one integer minimum is
 //    intersect_scene's strict '<' over the whole visiting sequence (mod.rs:598,649), no tie needs a second look.
-__device__ __forceinline__ unsigned long long walk_deferred_keys(const DevScene &S, vec3 o, vec3 d, const WalkQueue &Q,
+template <class NodePtr>
+__device__ __forceinline__ unsigned long long walk_deferred_keys(const DevScene &S, NodePtr nodes, vec3 o, vec3 d, const WalkQueue &Q,
                                                                  unsigned long long key, unsigned long long *wave_keys) {
     for (uint32_t q = 0; q < S.n_bvh_meshes; ++q) {
         PT_PHASE(kPhWalkGate);
@@ -1543,7 +1572,7 @@ __device__ __forceinline__ unsigned long long walk_deferred_keys(const DevScene 
         if (__builtin_amdgcn_ballot_w64(pass) == 0ull) continue;
         float mt = __builtin_inff();
         int32_t mid = -1;
-        bvh_closest_queue(S, S.bvh_nodes, Q, wave_keys, pass, o, d, bm.root, __uint_as_float((uint32_t)(key >> 32)), mt, mid);
+        bvh_closest_queue(S, nodes, Q, wave_keys, pass, o, d, bm.root, __uint_as_float((uint32_t)(key >> 32)), mt, mid);
         bool won = false;
         if (pass && mid >= 0) {
             const unsigned long long k2 = ((unsigned long long)__float_as_uint(mt) << 32) | S.tri_rank[mid];

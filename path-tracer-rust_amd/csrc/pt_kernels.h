@@ -20,6 +20,7 @@ struct RayQueue {
 };
 constexpr uint32_t kRayBytes = 40;
 constexpr uint32_t kWaveParkCap = 128;    // parked rays of a wave (k_pass_cand with walks: 63 left over + 64 new at most)
+constexpr uint32_t kWaveParkBytes = kWaveParkCap * (kRayBytes + 8u);  // the ray (40 B) and its key so far (8 B)
 constexpr uint32_t kWaveStackMax = 2048;  // slots of a wave's ray stack (k_pass_cand: a quarter of the stream's slice)
 inline size_t queue_bytes(size_t K, uint32_t cap) { return K * (size_t)cap * kRayBytes; }
 

@@ -589,27 +589,33 @@ __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, R
 // wave's parking area in global memory, its key in LDS), and 64 parked rays at a time are walked (bvh_closest_queue: the
 // wave's pending box tests as one queue), the closest triangle folded into the key by rank, shaded and pushed.
 // LDS of that form, between the per-wave candidate areas and the staged records:
-//   [per wave: walk queue (pass_cand_queue_bytes)][per wave: u64 key x 128 of the parked rays][per wave: u64 key x 64]
+//   [per wave: walk queue (pass_cand_queue_bytes)][per wave: u64 key x 64][BVH nodes (NLDS: a small tree's nodes, staged)]
+// (the parked rays' keys travel with the rays in the wave's parking area)
 constexpr uint32_t kCandParkCap = kWaveParkCap;  // 63 left over + 64 new at most
 // per wave: the walk queue (header + 8-byte entries: box tests from one end, leaves from the other), which is also where
 // the depth-first stacks (DevScene.bvh_stack entries x 64 lanes x u16, or u32 when a tree has 32 768 nodes or leaves) and
 // the leaf list of the rare second walk live
-constexpr uint32_t kWalkQueueBytes = 2560;  // 320 entries
+constexpr uint32_t kWalkQueueBytes = 2560;        // 320 entries
+constexpr uint32_t kWalkQueueBytesStaged = 2048;  // 256 entries: beside the workgroup's copy of the nodes (bvh_in_lds bit 2)
 __host__ __device__ inline size_t pass_cand_queue_bytes(const DevScene &S) {
     const size_t again = (size_t)S.bvh_stack * 64u * ((S.bvh_in_lds & 2u) ? 2u : 4u) + kLeafListCap * 4u;
-    return kWalkQueueHeader + (((again > kWalkQueueBytes ? again : kWalkQueueBytes) + 15) & ~(size_t)15);
+    const size_t q = (S.bvh_in_lds & 4u) ? kWalkQueueBytesStaged : kWalkQueueBytes;
+    return kWalkQueueHeader + (((again > q ? again : q) + 15) & ~(size_t)15);
 }
 __host__ __device__ inline size_t pass_cand_queues_bytes(const DevScene &S) { return (size_t)(kBlock / 64u) * pass_cand_queue_bytes(S); }
-constexpr size_t kCandParkBytes = kCandParkCap * 8u;                   // per wave: the parked rays' keys
 constexpr size_t kCandWalkKeyBytes = 64u * 8u;                         // per wave: the walkers' keys
-__host__ __device__ inline size_t pass_cand_bvh_bytes(const DevScene &S) {
-    return pass_cand_queues_bytes(S) + (size_t)(kBlock / 64u) * (kCandParkBytes + kCandWalkKeyBytes);
+// [the waves' walk queues][the waves' walk keys][the workgroup's copy of the BVH nodes, when they fit (bvh_in_lds bit 2)]
+__host__ __device__ inline size_t pass_cand_nodes_offset(const DevScene &S) {
+    return pass_cand_queues_bytes(S) + (size_t)(kBlock / 64u) * kCandWalkKeyBytes;
 }
-static_assert(kCandParkBytes % 16u == 0u && kCandWalkKeyBytes % 16u == 0u, "per-wave areas stay 16-byte aligned");
+__host__ __device__ inline size_t pass_cand_bvh_bytes(const DevScene &S) {
+    return pass_cand_nodes_offset(S) + ((S.bvh_in_lds & 4u) ? (size_t)S.n_bvh_nodes * sizeof(BvhNode) : 0u);
+}
+static_assert(kCandWalkKeyBytes % 16u == 0u && sizeof(BvhNode) % 16u == 0u, "per-wave areas stay 16-byte aligned");
 
 // (The workgroup's own copy of the nodes in LDS, in front of the stacks, was tried: mesh.json's 141 nodes are 9 KB, which
 // leaves room for three workgroups per CU instead of four - 16.1 against 17.8 G bounces/s.)
-template <bool STAGED, bool DEFER, bool BVH, bool PROBE>
+template <bool STAGED, bool DEFER, bool BVH, bool PROBE, bool NLDS = false>
 __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams F, RayQueue q0, RayQueue q1, uint32_t cap,
                                                          uint32_t s0, uint32_t s_here, uint32_t m,
                                                          unsigned long long *__restrict__ acc,
@@ -683,15 +689,19 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
             }
         }
     }
-    // BVH: the waves' walk queues, then this wave's parking area and walk keys
+    // BVH: the waves' walk queues, then the waves' walk keys, then (NLDS) the workgroup's copy of the BVH nodes
     char *const walk_lds = (reinterpret_cast<char *>(dyn_lds) + pass_lds_cand_offset(m, DEFER) + pass_lds_cand_bytes());
     unsigned long long *p_key = nullptr;
     unsigned long long *walk_keys = nullptr;
     WalkQueue wq{};
+    const BvhNode *const nodes_lds = reinterpret_cast<const BvhNode *>(walk_lds + pass_cand_nodes_offset(S));
+    if (BVH && NLDS) {  // a box test of the walk queue then waits for an LDS read instead of a 64-byte gather from L2
+        const uint4 *src = reinterpret_cast<const uint4 *>(S.bvh_nodes);
+        uint4 *dst = reinterpret_cast<uint4 *>(walk_lds + pass_cand_nodes_offset(S));
+        for (uint32_t k = tid; k < S.n_bvh_nodes * (uint32_t)(sizeof(BvhNode) / 16u); k += kBlock) dst[k] = src[k];
+    }
     if (BVH) {
-        char *wb = walk_lds + pass_cand_queues_bytes(S) + (size_t)(tid >> 6) * (kCandParkBytes + kCandWalkKeyBytes);
-        p_key = reinterpret_cast<unsigned long long *>(wb);
-        walk_keys = reinterpret_cast<unsigned long long *>(wb + kCandParkBytes);
+        walk_keys = reinterpret_cast<unsigned long long *>(walk_lds + pass_cand_queues_bytes(S) + (size_t)(tid >> 6) * kCandWalkKeyBytes);
         char *qb = walk_lds + (size_t)(tid >> 6) * pass_cand_queue_bytes(S);
         wq.redo = reinterpret_cast<uint32_t *>(qb);
         wq.ent = reinterpret_cast<uint2 *>(qb + kWalkQueueHeader);
@@ -738,9 +748,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
     qs.off_od1 = room * 32u;
     StreamSlice qpark{};  // BVH: the parked rays of the wave (container 1)
     if (BVH) {
-        qpark.base = q1.buf + (size_t)(b * 4u + wv) * kCandParkCap * kRayBytes;
+        qpark.base = q1.buf + (size_t)(b * 4u + wv) * kWaveParkBytes;
         qpark.off_tp = kCandParkCap * 16u;
         qpark.off_od1 = kCandParkCap * 32u;
+        p_key = reinterpret_cast<unsigned long long *>(qpark.base + kCandParkCap * kRayBytes);  // (the keys follow the rays)
     }
     if (!room_for_all && room < 512u) {  // (the host sizes the slices; never a hang)
         if (tid == 0) atomicOr(flags, 2u);
@@ -805,7 +816,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
         if (valid) {
             PathRay in;
             load_ray_slice(qpark, e, in.o, in.d, in.thr, word);
-            const unsigned long long key = walk_deferred_keys(S, in.o, in.d, wq, p_key[e], walk_keys);
+            unsigned long long key;
+            if constexpr (NLDS)
+                key = walk_deferred_keys(S, nodes_lds, in.o, in.d, wq, p_key[e], walk_keys);
+            else
+                key = walk_deferred_keys(S, S.bvh_nodes, in.o, in.d, wq, p_key[e], walk_keys);
             const uint32_t rank = (uint32_t)key;
             if (rank != 0xffffffffu) {
                 in.pix = lds_pix[word_pix(word)];
@@ -1574,11 +1589,21 @@ hipError_t launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const Fram
         const bool bvh = S.n_bvh_nodes != 0u;
         DevScene S2 = S;
         S2.bvh_in_lds &= ~1u;  // (nodes from global memory: PT_BVH_LDS asks for the staged k_intersect, not for this kernel)
-        const size_t walk = bvh ? pass_cand_bvh_bytes(S2) : 0u;
         const size_t rec_cand = (size_t)S.n_cand_pairs * sizeof(CandPairRec);
         const size_t rec_surf = (size_t)(S.n_objs + S.n_tris) * sizeof(SurfRec);
         // glass deferral: not with walks (their queues take its place in LDS; a walked ray is shaded in place anyway)
         const bool defer = !bvh && pass_lds_cand_offset(m, true) + pass_lds_cand_bytes() <= budget;
+        // walks: the nodes of a small tree are staged in LDS beside (smaller) walk queues when they fit with the candidate
+        // records (mesh.json: 141 nodes, 9 KB) - a box test of the walk queue waits for its node, and an LDS read comes back
+        // several times sooner than a 64-byte gather from L2
+        bool nodes_lds = false;
+        if (bvh && S.nodes_in_lds_ok) {
+            DevScene S3 = S2;
+            S3.bvh_in_lds |= 4u;
+            nodes_lds = pass_lds_cand_offset(m, false) + pass_lds_cand_bytes() + pass_cand_bvh_bytes(S3) + rec_cand <= budget;
+            if (nodes_lds) S2 = S3;
+        }
+        const size_t walk = bvh ? pass_cand_bvh_bytes(S2) : 0u;
         const size_t before = pass_lds_cand_offset(m, defer) + pass_lds_cand_bytes() + walk;
         S2.surf_staged = before + rec_cand + rec_surf <= budget ? 1u : 0u;
         // (without walks the records are staged whole or not at all; with walks the candidate records alone may be)
@@ -1592,17 +1617,17 @@ hipError_t launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const Fram
         }
         const size_t lds = before + (staged ? rec_cand + (S2.surf_staged ? rec_surf : (size_t)S2.surf_head * sizeof(SurfRec)) : 0u);
         // (more than 64 KB of dynamic LDS - wide deep trees with hundreds of pixels per stream - has to be asked for)
-#define PT_LAUNCH_CAND(ST, DF, BV)                                                                                     \
+#define PT_LAUNCH_CAND(ST, DF, BV, NL)                                                                                 \
     do {                                                                                                               \
         if (F.probe)                                                                                                   \
-            PT_LAUNCH_CAND2(ST, DF, BV, true);                                                                         \
+            PT_LAUNCH_CAND2(ST, DF, BV, true, NL);                                                                     \
         else                                                                                                           \
-            PT_LAUNCH_CAND2(ST, DF, BV, false);                                                                        \
+            PT_LAUNCH_CAND2(ST, DF, BV, false, NL);                                                                    \
     } while (0)
-#define PT_LAUNCH_CAND2(ST, DF, BV, PR)                                                                                   \
+#define PT_LAUNCH_CAND2(ST, DF, BV, PR, NL)                                                                               \
     do {                                                                                                               \
         if (lds > 64u * 1024u) {                                                                                       \
-            const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pass_cand<ST, DF, BV, PR>),     \
+            const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pass_cand<ST, DF, BV, PR, NL>), \
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
             if (ea != hipSuccess) {                                                                                    \
                 set_error("k_pass_cand needs " + std::to_string(lds) + " bytes of LDS per workgroup for this scene: " +  \
@@ -1610,20 +1635,22 @@ hipError_t launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const Fram
                 return ea;                                                                                             \
             }                                                                                                          \
         }                                                                                                              \
-        hipLaunchKernelGGL((k_pass_cand<ST, DF, BV, PR>), dim3(K), dim3(kBlock), lds, st, S2, F, q0, q1, cap, s0, s_here, m, acc, blk_rays, flags); \
+        hipLaunchKernelGGL((k_pass_cand<ST, DF, BV, PR, NL>), dim3(K), dim3(kBlock), lds, st, S2, F, q0, q1, cap, s0, s_here, m, acc, blk_rays, flags); \
     } while (0)
-        if (bvh && staged)
-            PT_LAUNCH_CAND(true, false, true);
+        if (bvh && staged && nodes_lds)
+            PT_LAUNCH_CAND(true, false, true, true);
+        else if (bvh && staged)
+            PT_LAUNCH_CAND(true, false, true, false);
         else if (bvh)
-            PT_LAUNCH_CAND(false, false, true);
+            PT_LAUNCH_CAND(false, false, true, false);
         else if (staged && defer)
-            PT_LAUNCH_CAND(true, true, false);
+            PT_LAUNCH_CAND(true, true, false, false);
         else if (staged)
-            PT_LAUNCH_CAND(true, false, false);
+            PT_LAUNCH_CAND(true, false, false, false);
         else if (defer)
-            PT_LAUNCH_CAND(false, true, false);
+            PT_LAUNCH_CAND(false, true, false, false);
         else
-            PT_LAUNCH_CAND(false, false, false);
+            PT_LAUNCH_CAND(false, false, false, false);
 #undef PT_LAUNCH_CAND
 #undef PT_LAUNCH_CAND2
         return hipSuccess;

@@ -1489,9 +1489,41 @@ def _render_dev(L, ctx, sc, w, h, spp, seed, flags=0, rays_per_pass=0):
     return host, st
 
 
+def test_small_wave_stacks_hold_primaries_back(gpu):
+    """k_pass_cand's waves keep their waiting rays on stacks of 2048 slots, where the bound on what may ever wait (`phi`,
+    DESIGN section 3) never holds a wave back.  With stacks of 512 slots (PT_WAVE_STACK) it does all the time - primaries start
+    only when nothing waits - and a wave pops fewer than 64 rays whenever its primaries are held back: the other half of the
+    loop's decisions.  Same frame bit for bit, same bounce count, no overflow - on cornell.json (glass deferral in the bound)
+    and on mesh.json (parked rays in the bound), with streams long enough that their whole share does not fit the stack."""
+    L, _ = gpu
+    for sid, (w, h, spp) in (("cornell", (256, 192, 384)), ("mesh", (256, 192, 256))):
+        sc = ptlib.load_scene_py(ptlib.scene_path(sid))
+        res = {}
+        for name, env in (("2048", {}), ("512", {"PT_WAVE_STACK": "512"})):
+            old = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            try:
+                ctx = C.c_void_p()
+                assert L.pt_ctx_create(0, C.byref(ctx)) == 0  # the tuning variables are read here
+            finally:
+                for k, v in old.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+            assert L.pt_ctx_set_scene(ctx, C.byref(sc.cam), sc.objs, sc.n_objs, sc.tris, sc.n_tris) == 0, L.pt_last_error()
+            assert L.pt_ctx_pass_kernel(ctx, 0).decode().startswith("k_pass_cand")
+            img, st = _render_dev(L, ctx, sc, w, h, spp, 9)
+            L.pt_ctx_destroy(ctx)
+            res[name] = (img, st.ray_bounces)
+        assert res["512"][1] == res["2048"][1], sid
+        assert np.array_equal(res["512"][0], res["2048"][0]), sid
+
+
 def test_memory_budget_changes_the_passes_not_the_image(gpu):
-    """pt_ctx_set_memory_budget: 8 MiB of ray queues hold 23 831 primary rays (352 B each) - one sample per pixel and pass
-    on a 128x96 frame instead of all 64 in one pass.  Same bits, same bounce count."""
+    """pt_ctx_set_memory_budget: 8 MiB is less than the wave stacks of the 64-sample pass of a 128x96 frame take (2048 streams x
+    4 waves x 512 slots x 40 B = 168 MB), so the pass is halved down to one sample per pixel and pass (the smallest stacks, 128
+    slots per wave) instead of all 64 in one pass.  Same bits, same bounce count."""
     L, ctx = gpu
     sc = ptlib.load_scene_py(ptlib.scene_path("cornell"))
     set_scene(gpu, sc)
@@ -1509,7 +1541,7 @@ def test_memory_budget_changes_the_passes_not_the_image(gpu):
 
 def test_default_pass_size_is_shared_by_pipelines_and_ranks(gpu):
     """Eight pipelines (PT_FLAG_PIPELINES) and eight ranks of pt_render_multi on this box's ONE GPU with the default
-    rays_per_pass on the baseline frame size: each context sizes its ray queues to an eighth of the default (round 2: 8 x 36 GB
+    rays_per_pass on the baseline frame size: each context sizes its passes to an eighth of the default (round 2: 8 x 36 GB
     of queues, PT_ERR_HIP on a 288 GB device).  Same bits as the single pipeline."""
     L, ctx = gpu
     sc = ptlib.load_scene_py(ptlib.scene_path("cornell"))
