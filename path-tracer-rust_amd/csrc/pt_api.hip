@@ -79,6 +79,8 @@ struct Tuning {
     uint64_t streams = 0;      // PT_STREAMS: ray streams per pass (0 = derived from the frame)
     uint32_t per_stream = 0;   // PT_PER_STREAM: primary rays per stream and pass that k_pass_cand's stream count aims at (0 = default)
     uint64_t rays_per_pass = 0;  // PT_RAYS_PER_PASS: the default of pt_config.rays_per_pass (probes; 0 = the library's)
+    bool glass_defer = false;    // PT_GLASS_DEFER=1: k_pass_cand collects glass hits per wave and shades them 64 at a time (A/B: it
+                                 // paid with levels, it does not without)
     bool nodes_lds = true;       // PT_NODES_LDS=0: k_pass_cand with walks reads the BVH nodes from global memory even when they
                                  // would fit its LDS (A/B)
     uint32_t wave_stack = 0;     // PT_WAVE_STACK=n: k_pass_cand's stacks hold n slots (a power of two, 512 <= n < kWaveStackMax)
@@ -103,6 +105,7 @@ static Tuning read_tuning() {
     t.per_stream = (uint32_t)num("PT_PER_STREAM", 0);
     t.rays_per_pass = (uint64_t)num("PT_RAYS_PER_PASS", 0);
     t.nodes_lds = num("PT_NODES_LDS", 1) != 0;
+    t.glass_defer = num("PT_GLASS_DEFER", 0) != 0;
     {
         const long long ws = num("PT_WAVE_STACK", 0);
         if (ws >= 512 && ws < (long long)kWaveStackMax && (ws & (ws - 1)) == 0) t.wave_stack = (uint32_t)ws;
@@ -843,6 +846,7 @@ int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uin
     c->scene.n_other_pairs = fs.n_other_pairs;
     c->scene.n_flat_exact = fs.n_flat_exact;
     c->scene.nodes_in_lds_ok = c->tune.nodes_lds ? 1u : 0u;
+    c->scene.glass_defer_ok = c->tune.glass_defer ? 1u : 0u;
     c->cand_ok = fs.cand_ok;
     c->scene.cand_staged = 0u;
     c->scene.surf_staged = 0u;

@@ -215,6 +215,7 @@ struct DevScene {
     uint32_t n_sph_pairs, n_flat_pairs, n_cand_pairs;
     uint32_t n_other_pairs;         // cand_pairs [0, n_other_pairs) have no filter: candidates for every ray
     uint32_t n_flat_exact;          // flat_pairs [0, n_flat_exact) have sign_exact set
+    uint32_t glass_defer_ok;        // k_pass_cand may defer glass hits to dense batches (PT_GLASS_DEFER=1; default: shaded in place)
     uint32_t nodes_in_lds_ok;       // k_pass_cand with walks may stage the BVH nodes in LDS when they fit (PT_NODES_LDS=0: never)
     uint32_t cand_scan;             // 1: k_pass uses the candidate scan
     uint32_t cand_staged;           // 1: the workgroup holds cand_pairs in LDS

@@ -960,6 +960,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
                     PT_PHASE_PIN(sf.x.x);
                     shade_surface<DEFER ? kShadeDeferRefract : kShadeAll>(P, pr, sf, so);
                     PT_PHASE(kPhEmit);
+                    // (Collecting the hits on emitters per wave and adding them 64 at a time - 16 B per entry, dense fixed-point
+                    // conversions and LDS atomics - was measured once the glass deferral had left its LDS free: +0.45 %, not kept.)
                     if (so.emits) add_radiance_lds(lds_acc, m, word_pix(prev_word), so.contrib);
                 }
             }
@@ -1592,7 +1594,11 @@ hipError_t launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const Fram
         const size_t rec_cand = (size_t)S.n_cand_pairs * sizeof(CandPairRec);
         const size_t rec_surf = (size_t)(S.n_objs + S.n_tris) * sizeof(SurfRec);
         // glass deferral: not with walks (their queues take its place in LDS; a walked ray is shaded in place anyway)
-        const bool defer = !bvh && pass_lds_cand_offset(m, true) + pass_lds_cand_bytes() <= budget;
+        // (Without levels the deferral no longer pays: a chunk mixes rays of every depth and nearly every trip shades some glass
+        // anyway - shading it in place, 46.5 against 46.05 G bounces/s on cornell, builds alternated; PT_GLASS_DEFER=1 brings
+        // the buffers back for that comparison.  Five waves per SIMD in the LDS this frees: 96 VGPRs with 91 values spilled,
+        // 26.3 G.)
+        const bool defer = !bvh && S.glass_defer_ok && pass_lds_cand_offset(m, true) + pass_lds_cand_bytes() <= budget;
         // walks: the nodes of a small tree are staged in LDS beside (smaller) walk queues when they fit with the candidate
         // records (mesh.json: 141 nodes, 9 KB) - a box test of the walk queue waits for its node, and an LDS read comes back
         // several times sooner than a 64-byte gather from L2
