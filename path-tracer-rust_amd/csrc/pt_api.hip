@@ -367,10 +367,9 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
         m = (uint32_t)((npix + k_target - 1) / k_target);
         if (m == 0) m = 1;
         if (m > kMaxStreamPixels) m = kMaxStreamPixels;
-        // k_pass_cand: a stream's accumulators and pixel tables (36 B per pixel) share the workgroup's 40 KB of LDS with the
-        // glass-deferral buffers and the staged records, which fit up to 72 pixels on the bench scene: frames of few samples
-        // get more, shorter streams rather than a kernel without them (1024x768 @128: 12 288 streams of 64 pixels, not 4 096
-        // of 192)
+        // k_pass_cand: frames of few samples get more, shorter streams rather than a handful of workgroups per CU slot, each
+        // with hundreds of pixels' accumulators and tables (36 B per pixel) in LDS (1024x768 @128: 12 288 streams of 64
+        // pixels, not 4 096 of 192)
         if (stack_form && !c->tune.streams && m > 64u) m = 64u;
         // A launch runs its workgroups in rounds of as many as the chip holds (four per CU); a stream's work grows with its m
         // pixels, so a launch takes about ceil(K / resident) x m: among the m within -15 % / +20 % of the tuned size take the

@@ -583,7 +583,8 @@ __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, R
 // origin and direction into the chunk's slots in LDS, tests the spheres, runs the filters and queues the candidates; full
 // batches of 64 candidates are run as the ring fills; then every candidate of the chunk started in the trip BEFORE has been
 // through a batch (they were the oldest entries of the ring), so those rays take their hit from their key, are shaded and
-// their continuations pushed.  Accumulators and the final flush are k_pass's; glass hits are deferred per wave as in k_pass.
+// their continuations pushed.  Accumulators and the final flush are k_pass's; glass hits are shaded in place (DEFER, the per-wave
+// deferral of k_pass, is an A/B switch here: launch_pass).
 // BVH = true (scenes with BVH meshes): when a ray is finished - its key holds the best of the spheres and of the candidate
 // records - bvh_wants decides whether it has to walk a BVH mesh; such a ray is not shaded but PARKED per wave (the ray in the
 // wave's parking area in global memory, its key in LDS), and 64 parked rays at a time are walked (bvh_closest_queue: the

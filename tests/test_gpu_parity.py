@@ -1494,12 +1494,15 @@ def test_small_wave_stacks_hold_primaries_back(gpu):
     DESIGN section 3) never holds a wave back.  With stacks of 512 slots (PT_WAVE_STACK) it does all the time - primaries start
     only when nothing waits - and a wave pops fewer than 64 rays whenever its primaries are held back: the other half of the
     loop's decisions.  Same frame bit for bit, same bounce count, no overflow - on cornell.json (glass deferral in the bound)
-    and on mesh.json (parked rays in the bound), with streams long enough that their whole share does not fit the stack."""
+    and on mesh.json (parked rays in the bound), with streams long enough that their whole share does not fit the stack.
+    Two more switches of the same kernel, same bits: glass hits collected per wave and shaded 64 at a time (PT_GLASS_DEFER=1, the
+    default until the levels went) and the BVH nodes read through L2 instead of staged in LDS (PT_NODES_LDS=0)."""
     L, _ = gpu
     for sid, (w, h, spp) in (("cornell", (256, 192, 384)), ("mesh", (256, 192, 256))):
         sc = ptlib.load_scene_py(ptlib.scene_path(sid))
         res = {}
-        for name, env in (("2048", {}), ("512", {"PT_WAVE_STACK": "512"})):
+        for name, env in (("2048", {}), ("512", {"PT_WAVE_STACK": "512"}), ("glass deferred", {"PT_GLASS_DEFER": "1"}),
+                          ("nodes from L2", {"PT_NODES_LDS": "0"})):
             old = {k: os.environ.get(k) for k in env}
             os.environ.update(env)
             try:
@@ -1516,8 +1519,9 @@ def test_small_wave_stacks_hold_primaries_back(gpu):
             img, st = _render_dev(L, ctx, sc, w, h, spp, 9)
             L.pt_ctx_destroy(ctx)
             res[name] = (img, st.ray_bounces)
-        assert res["512"][1] == res["2048"][1], sid
-        assert np.array_equal(res["512"][0], res["2048"][0]), sid
+        for name in res:
+            assert res[name][1] == res["2048"][1], (sid, name)
+            assert np.array_equal(res[name][0], res["2048"][0]), (sid, name)
 
 
 def test_memory_budget_changes_the_passes_not_the_image(gpu):
