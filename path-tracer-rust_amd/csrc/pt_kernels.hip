@@ -1601,8 +1601,9 @@ hipError_t launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const Fram
         // 26.3 G.)
         const bool defer = !bvh && S.glass_defer_ok && pass_lds_cand_offset(m, true) + pass_lds_cand_bytes() <= budget;
         // walks: the nodes of a small tree are staged in LDS beside (smaller) walk queues when they fit with the candidate
-        // records (mesh.json: 141 nodes, 9 KB) - a box test of the walk queue waits for its node, and an LDS read comes back
-        // several times sooner than a 64-byte gather from L2
+        // records (mesh.json: 171 nodes, 10.9 KB: up to 24 pixels per stream).  Measured: no gain and no loss against the
+        // gathers from L2 (26.74 / 26.72 G bounces/s) - a box-test batch waits for its turn at the SIMD, not for its node -
+        // so streams are not shortened to make room for it
         bool nodes_lds = false;
         if (bvh && S.nodes_in_lds_ok) {
             DevScene S3 = S2;

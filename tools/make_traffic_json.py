@@ -39,10 +39,13 @@ NOTE = ("insts_per_ray = SQ_INSTS_VALU x 64 / rays (dynamic); issue_slots_frac =
         "and the no-packed-instruction A/B of DESIGN section 4); avg_cost = sum(count x cost) / count")
 ASM = os.path.join(ROOT, "path-tracer-rust_amd", "pt_kernels.s")
 # kernel name in the profile -> symbol fragment in the listing (most specific first)
-# (k_pass_cand<STAGED, DEFER, BVH>: "true, true, false" is the bench scene's, "true, false, true" mesh.json's: pt_ctx_pass_kernel
+# (k_pass_cand<STAGED, DEFER, BVH, PROBE, NLDS>: "true, false, false, false, false" is the bench scene's (glass in place),
+# "true, false, true, false, true" mesh.json's (nodes staged): pt_ctx_pass_kernel
 # calls the latter k_pass_cand_bvh, and bench.py looks its traffic up under that name)
-KERNELS = [("k_pass_cand<true, false, true, false>", "k_pass_candILb1ELb0ELb1ELb0", "k_pass_cand_bvh"),
-           ("k_pass_cand<true, true, false, false>", "k_pass_candILb1ELb1ELb0ELb0", "k_pass_cand"), ("k_pass_bvh", "k_pass_bvhILb0", None),
+KERNELS = [("k_pass_cand<true, false, true, false, true>", "k_pass_candILb1ELb0ELb1ELb0ELb1", "k_pass_cand_bvh"),
+           ("k_pass_cand<true, false, true, false, false>", "k_pass_candILb1ELb0ELb1ELb0ELb0", "k_pass_cand_bvh"),
+           ("k_pass_cand<true, false, false, false, false>", "k_pass_candILb1ELb0ELb0ELb0ELb0", "k_pass_cand"),
+           ("k_pass_cand<true, true, false, false, false>", "k_pass_candILb1ELb1ELb0ELb0ELb0", "k_pass_cand"), ("k_pass_bvh", "k_pass_bvhILb0", None),
            ("k_pass<", "k_passILb1ELb0", None), ("k_intersect_cand", "k_intersect_candILb1", None),
            ("k_intersect<", "k_intersectILb0", "k_intersect"), ("k_mega", "k_megaILb0ELb0", None)]
 done = {}
