@@ -1,6 +1,11 @@
 // pt_kernels.hip — gfx950 kernels of the wavefront radiance() pipeline and the persistent megakernel.
 //
-// Wavefront pipeline (one pass = P primary rays), scenes without BVH meshes:
+// Wavefront pipeline (one pass = P primary rays):
+//   k_pass_cand                        THE DEFAULT: the whole pass in one launch, candidate scan instead of testing every
+//                                      triangle (pt_device.h), and no levels - every wave of a workgroup (= ray stream: a set
+//                                      of pixels, all samples of the pass) keeps its waiting rays on a stack of its own in
+//                                      global memory, pops 64 or starts 64 primary rays; BVH meshes: walks parked per wave
+// the level-by-level forms (PT_CAND_SCAN=0 / PT_FLAG_NO_BVH / PT_CAND_BVH=0), scenes without BVH meshes:
 //   k_pass                             the whole pass in one launch: per workgroup (= ray stream) the primary rays
 //                                      (render_pixel, mod.rs:812-843), then level by level closest hit
 //                                      (intersect_scene, mod.rs:631-659), roulette / emission / BRDF sample / refract
@@ -651,8 +656,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
     // advance by (64 % mb, 64 / mb) with a carry - no division per trip.
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const uint32_t cap_w = cap >> 2;
-    const uint32_t n0 = mb * s_here;                  // level-0 rays of the stream
-    const uint32_t quarter = (n0 + 3u) >> 2;               // ... of a wave (the last may have fewer)
+    const uint32_t n0 = mb * s_here;         // primary rays of the stream
+    const uint32_t quarter = (n0 + 3u) >> 2;  // ... of a wave (the last may have fewer)
     const uint32_t base0 = wv * quarter < n0 ? wv * quarter : n0;
     const uint32_t step_q = 64u / mb, step_r = 64u % mb;
     uint32_t gen_pj = (base0 + lane) % mb, gen_sj = (base0 + lane) / mb;
