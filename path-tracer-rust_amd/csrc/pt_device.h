@@ -92,7 +92,7 @@ constexpr uint32_t kBvhMinTris = 16;        // meshes with fewer triangles are s
 // Dense leaf batches make a pair test cheaper than a depth-first node step, so the last levels of the tree are better
 // spent as tests (k_pass_bvh, depth-first walks: 1 record per leaf 14.4, 2: 15.4, 4: 15.5, 8: 15.2 G bounces/s on
 // mesh.json).  With the box tests dense too (k_pass_cand's walk queue) the balance moves back a little:
-// 1: 19.5, 2: 20.0, 3: 20.2, 4: 19.8.
+// 1: 19.5, 2: 20.0, 3: 20.2, 4: 19.8; and without levels (round 3) 2: 26.5, 3: 26.8, 4: 26.2 (640 000 triangles: 25.9 / 25.6 / 25.3).
 #ifndef PT_BVH_LEAF_PAIRS
 #define PT_BVH_LEAF_PAIRS 3
 #endif
