@@ -21,7 +21,9 @@ struct RayQueue {
 constexpr uint32_t kRayBytes = 40;
 constexpr uint32_t kWaveParkCap = 128;    // parked rays of a wave (k_pass_cand with walks: 63 left over + 64 new at most)
 constexpr uint32_t kWaveParkBytes = kWaveParkCap * (kRayBytes + 8u);  // the ray (40 B) and its key so far (8 B)
-constexpr uint32_t kWaveStackMax = 2048;  // slots of a wave's ray stack (k_pass_cand: a quarter of the stream's slice)
+constexpr uint32_t kWaveStackMax = 1024;  // slots of a wave's ray stack (k_pass_cand: a quarter of the stream's slice).  What may
+                                          // ever wait is bounded by phi (k_pass_cand); with 1024 slots a wave that is about to
+                                          // start primaries (fewer than 64 rays waiting, fewer than 64 parked) is never held back
 inline size_t queue_bytes(size_t K, uint32_t cap) { return K * (size_t)cap * kRayBytes; }
 
 // one whole pass of a scene without BVH meshes in one launch (see k_pass)

@@ -1490,7 +1490,7 @@ def _render_dev(L, ctx, sc, w, h, spp, seed, flags=0, rays_per_pass=0):
 
 
 def test_small_wave_stacks_hold_primaries_back(gpu):
-    """k_pass_cand's waves keep their waiting rays on stacks of 2048 slots, where the bound on what may ever wait (`phi`,
+    """k_pass_cand's waves keep their waiting rays on stacks of 1024 slots, where the bound on what may ever wait (`phi`,
     DESIGN section 3) never holds a wave back.  With stacks of 512 slots (PT_WAVE_STACK) it does all the time - primaries start
     only when nothing waits - and a wave pops fewer than 64 rays whenever its primaries are held back: the other half of the
     loop's decisions.  Same frame bit for bit, same bounce count, no overflow - on cornell.json (glass deferral in the bound)
@@ -1501,7 +1501,7 @@ def test_small_wave_stacks_hold_primaries_back(gpu):
     for sid, (w, h, spp) in (("cornell", (256, 192, 384)), ("mesh", (256, 192, 256))):
         sc = ptlib.load_scene_py(ptlib.scene_path(sid))
         res = {}
-        for name, env in (("2048", {}), ("512", {"PT_WAVE_STACK": "512"}), ("glass deferred", {"PT_GLASS_DEFER": "1"}),
+        for name, env in (("1024", {}), ("512", {"PT_WAVE_STACK": "512"}), ("glass deferred", {"PT_GLASS_DEFER": "1"}),
                           ("nodes from L2", {"PT_NODES_LDS": "0"})):
             old = {k: os.environ.get(k) for k in env}
             os.environ.update(env)
@@ -1520,8 +1520,8 @@ def test_small_wave_stacks_hold_primaries_back(gpu):
             L.pt_ctx_destroy(ctx)
             res[name] = (img, st.ray_bounces)
         for name in res:
-            assert res[name][1] == res["2048"][1], (sid, name)
-            assert np.array_equal(res[name][0], res["2048"][0]), (sid, name)
+            assert res[name][1] == res["1024"][1], (sid, name)
+            assert np.array_equal(res[name][0], res["1024"][0]), (sid, name)
 
 
 def test_memory_budget_changes_the_passes_not_the_image(gpu):
@@ -1569,14 +1569,14 @@ def test_default_pass_size_is_shared_by_pipelines_and_ranks(gpu):
 def test_out_of_device_memory_halves_the_pass(gpu):
     """A pass whose ray queues do not fit what is left of the device is halved until it does (DevBuf::ensure reports the
     failed allocation, render_wavefront retries): nearly all of the HBM is taken by other allocations first (the refused one
-    among them must not come back as the frame's error), then a frame is asked for in ONE pass of 512 samples - 16 Ki streams
-    with 5.4 GB of wave stacks where 2 to 4 GiB are free.  Same bits as the frame rendered at leisure."""
+    among them must not come back as the frame's error), then a frame is asked for in ONE pass of 2048 samples - 64 Ki streams
+    with 10.7 GB of wave stacks where 2 to 4 GiB are free.  Same bits as the frame rendered at leisure."""
     L, _ = gpu
     sc = ptlib.load_scene_py(ptlib.scene_path("cornell"))
     ctx = C.c_void_p()
     assert L.pt_ctx_create(0, C.byref(ctx)) == 0, L.pt_last_error()
     assert L.pt_ctx_set_scene(ctx, C.byref(sc.cam), sc.objs, sc.n_objs, sc.tris, sc.n_tris) == 0
-    w, h, spp = 1024, 768, 512
+    w, h, spp = 1024, 768, 2048
     want, st0 = _render_dev(L, ctx, sc, w, h, spp, 6, rays_per_pass=8 << 20)
     hogs = []
     try:
@@ -1587,12 +1587,12 @@ def test_out_of_device_memory_halves_the_pass(gpu):
             hogs.append(p)
         assert len(hogs) >= 32, "could not even take 64 GiB"
         L.pt_device_free(0, hogs.pop())  # leave 2 GiB (+ the remainder, less than 2 GiB) free
-        got, st1 = _render_dev(L, ctx, sc, w, h, spp, 6, rays_per_pass=1 << 30)
+        got, st1 = _render_dev(L, ctx, sc, w, h, spp, 6, rays_per_pass=1 << 31)
     finally:
         for p in hogs:
             L.pt_device_free(0, p)
         L.pt_ctx_destroy(ctx)
-    assert st1.passes > 1, st1.passes  # 1 Gi rays would have been one pass
+    assert st1.passes > 1, st1.passes  # 2 Gi rays would have been one pass
     assert st1.ray_bounces == st0.ray_bounces and np.array_equal(got, want)
 
 
