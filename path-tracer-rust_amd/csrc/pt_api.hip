@@ -336,93 +336,39 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
     }
     uint32_t spp_pass = 0, m = 0, K = 0, cap = 0;
     for (;;) {
-        spp_pass = (uint32_t)(want / npix);
-        if (spp_pass == 0) spp_pass = 1;
-        if (spp_pass > cfg->spp) spp_pass = cfg->spp;
-        if (spp_pass > kMaxPassSpp) spp_pass = kMaxPassSpp;  // sample-in-pass field of the stream bookkeeping word
-        if (stack_form && spp_pass < cfg->spp) {
-            // passes of equal length (4096 samples in passes of 682 at most would end with one of 4 samples: short streams,
-            // a launch that cannot fill the chip); a pass may be up to a twentieth longer than asked for that - k_pass_cand's
-            // memory does not grow with the pass
-            const uint32_t stretch = spp_pass + spp_pass / 20u;
-            const uint32_t n_eq = (cfg->spp + stretch - 1u) / stretch;
-            const uint32_t eq = (cfg->spp + n_eq - 1u) / n_eq;
-            if (eq <= kMaxPassSpp) spp_pass = eq;
+        host::PassPlanIn pin;
+        pin.npix = npix;
+        pin.spp = cfg->spp;
+        pin.want = want;
+        pin.want_is_default = !cfg->rays_per_pass;
+        pin.stack_form = stack_form;
+        pin.stack_park = stack_park;
+        pin.cand_scan = c->scene.cand_scan != 0u;
+        pin.has_bvh = c->scene.n_bvh_nodes != 0u;
+        pin.streams = c->tune.streams;
+        pin.per_stream = c->tune.per_stream;
+        pin.wave_stack = c->tune.wave_stack;
+        pin.n_cus = c->n_cus;
+        pin.stack_budget = stack_budget;
+        host::PassPlan plan;
+        uint64_t want_next = want;
+        const int pr = host::plan_pass(pin, plan, &want_next);  // (the arithmetic and its measurements: pt_host.cpp)
+        if (pr == host::kPlanRetry) {
+            want = want_next;
+            continue;
         }
-        // Streams: many more than the 2048 workgroups the chip holds at once, so that the dispatcher keeps every CU busy
-        // until a launch ends, but each still a few launches' worth of work for its workgroup - about 2048 primary rays
-        // per stream and pass (measured on cornell 1024x768: 2048 streams 22.0, 8192 24.3, 16384 24.7, 65536 23.2 G
-        // bounces/s).  A stream owns at most kMaxStreamPixels pixels (their accumulators live in LDS inside k_shade).
-        // (scenes with a BVH stage its nodes into LDS once per workgroup: twice the work per stream; mesh.json 2048 streams
-        // 7.3, 8192 7.6, 16384 7.0)
-        // (candidate scan, four waves per SIMD: 12288 streams 35.8, 16384 35.4, 8192 32.2, 24576 33.7 G bounces/s)
-        // (candidate scan with walks, mesh.json: 24576 streams 19.8, 26624 20.5, 28672 20.1, 30720 20.3, 32768 19.9 G bounces/s)
-        // (k_pass_cand's waves run without levels: a wave's first and last trips - the stack fills, the last rays die - are
-        // the only ones that are not full, so its streams are long)
-        const uint64_t per_stream = stack_form ? (uint64_t)(c->tune.per_stream ? c->tune.per_stream : 24576u)
-                                               : (c->scene.n_bvh_nodes != 0u ? 4096u : 2048u);
-        uint64_t k_target = ((uint64_t)npix * spp_pass + per_stream - 1u) / per_stream;
-        if (k_target < 2048u) k_target = 2048u;
-        if (c->tune.streams) k_target = c->tune.streams;
-        m = (uint32_t)((npix + k_target - 1) / k_target);
-        if (m == 0) m = 1;
-        if (m > kMaxStreamPixels) m = kMaxStreamPixels;
-        // k_pass_cand: frames of few samples get more, shorter streams rather than a handful of workgroups per CU slot, each
-        // with hundreds of pixels' accumulators and tables (36 B per pixel) in LDS (1024x768 @128: 12 288 streams of 64
-        // pixels, not 4 096 of 192)
-        if (stack_form && !c->tune.streams && m > 64u) m = 64u;
-        // A launch runs its workgroups in rounds of as many as the chip holds (four per CU); a stream's work grows with its m
-        // pixels, so a launch takes about ceil(K / resident) x m: among the m within -15 % / +20 % of the tuned size take the
-        // one for which that is smallest (cornell 1024x768: m = 21 -> 24, 37 450 streams in 36.6 rounds -> 32 768 in 32.0,
-        // 37.3 -> 37.7 G bounces/s).  Not for scenes with walks, whose streams differ too much in length for rounds to show
-        // (mesh.json: 24.0 rounds are slower than 25.6).
-        if (c->scene.cand_scan && c->scene.n_bvh_nodes == 0u && !c->tune.streams && c->n_cus != 0u && m >= 8u) {
-            const uint64_t resident = (uint64_t)c->n_cus * 4u;
-            uint32_t best_m = m;
-            uint64_t best_cost = ~0ull;
-            for (uint32_t mm = m - m * 15u / 100u; mm <= m + m / 5u && mm <= (stack_form ? 72u : kMaxStreamPixels); ++mm) {
-                const uint64_t kk = (npix + mm - 1u) / mm;
-                const uint64_t cost = ((kk + resident - 1u) / resident) * mm;
-                if (cost < best_cost || (cost == best_cost && (mm > m ? mm - m : m - mm) < (best_m > m ? best_m - m : m - best_m))) {
-                    best_cost = cost;
-                    best_m = mm;
-                }
-            }
-            m = best_m;
-        }
-        K = (uint32_t)((npix + m - 1) / m);
-        // a primary ray has at most 4 descendants alive at one depth (two refract splits, mod.rs:760); k_pass_cand gives each
-        // of its four waves a quarter of the slice and ceil(n / 4) of the stream's n primaries: 4 * ceil(n / 4) <= n + 3
-        uint64_t cap64 = (4ull * m * spp_pass + 16u + kBlock - 1) / kBlock * kBlock;
-        // k_pass_cand keeps a wave's waiting rays on a stack of at most kWaveStackMax slots (a quarter of the stream's slice
-        // per wave, a power of two of at least 128 slots - the parking area of a wave's walks has the same size)
-        if (stack_form) {
-            const uint64_t need_w = (uint64_t)m * spp_pass + 8u;
-            uint64_t cap_w = 128u;
-            const uint64_t stack_max = c->tune.wave_stack ? c->tune.wave_stack : kWaveStackMax;
-            while (cap_w < need_w && cap_w < stack_max) cap_w *= 2u;
-            cap64 = 4u * cap_w;
-            if (stack_budget && queue_bytes(K, (uint32_t)cap64) + (stack_park ? (size_t)K * 4u * kWaveParkBytes : 0u) > stack_budget &&
-                spp_pass > 1u) {  // the default pass does not fit the budget: smaller passes have fewer streams or smaller stacks
-                want = (uint64_t)npix * (spp_pass / 2u);
-                continue;
-            }
-        }
-        // (slot indices are 32-bit over the whole queue, byte offsets 32-bit inside a stream's slice of cap * 40 bytes)
-        if (cap64 * K > 0xffffffffull / 2 || cap64 * kRayBytes > 0xffffffffull) {
-            if (spp_pass > 1u && !cfg->rays_per_pass) {  // (a default this large only on a device with > 680 GB)
-                want /= 2;
-                continue;
-            }
+        if (pr != host::kPlanOk) {
             set_error("rays per pass too large");
             return PT_ERR_INVALID;
         }
-        cap = (uint32_t)cap64;
+        spp_pass = plan.spp_pass;
+        m = plan.m;
+        K = plan.K;
+        cap = plan.cap;
         const size_t slots = (size_t)K * cap;
         int rc = PT_OK;
-        rc = c->q_buf[0].ensure(queue_bytes(K, cap), true);
-        if (!rc && !stack_form) rc = c->q_buf[1].ensure(queue_bytes(K, cap), true);
-        if (!rc && stack_park) rc = c->q_buf[1].ensure((size_t)K * 4u * kWaveParkBytes, true);
+        rc = c->q_buf[0].ensure(plan.bytes0, true);
+        if (!rc && plan.bytes1) rc = c->q_buf[1].ensure(plan.bytes1, true);
         // scenes without BVH meshes run a pass as one launch (k_pass), BVH scenes as k_pass_bvh unless their nodes are staged
         // in LDS; PT_FLAG_SEPARATE_KERNELS / PT_PASS_KERNEL=0 / PT_PASS_BVH=0 keep the three-kernel form (A/B, profiling).
         // Only that form needs the hit records: k_pass keeps hits in registers.

@@ -323,6 +323,15 @@ PT_HD uint32_t stream_pixel_count(uint32_t npix, uint32_t n_streams, uint32_t b)
 // most 1024 pixels and a pass holds at most 32767 samples of a pixel, so both are stored relative to the stream /
 // pass: pixel-in-stream (10 bits) | sample-in-pass (15) | depth (4) | branch (3).
 constexpr uint32_t kMaxPassSpp = 32767u;
+constexpr uint32_t kBlock = 256;             // 4 waves of 64: the workgroup of the stream kernels
+constexpr uint32_t kMaxStreamPixels = 1024;  // pixels owned by one stream (24 KiB of LDS accumulators at most)
+constexpr uint32_t kRayBytes = 40;
+constexpr uint32_t kWaveParkCap = 128;    // parked rays of a wave (k_pass_cand with walks: 63 left over + 64 new at most)
+constexpr uint32_t kWaveParkBytes = kWaveParkCap * (kRayBytes + 8u);  // the ray (40 B) and its key so far (8 B)
+constexpr uint32_t kWaveStackMax = 1024;  // slots of a wave's ray stack (k_pass_cand: a quarter of the stream's slice).  What may
+                                          // ever wait is bounded by phi (k_pass_cand); with 1024 slots a wave that is about to
+                                          // start primaries (fewer than 64 rays waiting, fewer than 64 parked) is never held back
+PT_HD size_t queue_bytes(size_t K, uint32_t cap) { return K * (size_t)cap * kRayBytes; }
 PT_HD uint32_t pack_word(uint32_t pix_in_stream, uint32_t sample_in_pass, uint32_t depth, uint32_t branch) {
     return (pix_in_stream & 1023u) | ((sample_in_pass & 32767u) << 10) | ((depth & 15u) << 25) | (branch << 29);
 }

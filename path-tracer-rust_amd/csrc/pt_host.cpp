@@ -629,5 +629,101 @@ bool flatten_scene(const pt_camera &cam, const pt_object *objs, uint32_t n_objs,
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Passes and streams of a wavefront frame (see render_wavefront for how the plan is used, and for the retry on a failed
+// allocation).
+int plan_pass(const PassPlanIn &in, PassPlan &out, uint64_t *want_next) {
+    const uint64_t npix = in.npix;
+    uint32_t spp_pass = (uint32_t)std::min<uint64_t>(in.want / (npix ? npix : 1u), 0xffffffffull);
+    if (spp_pass == 0) spp_pass = 1;
+    if (spp_pass > in.spp) spp_pass = in.spp;
+    if (spp_pass > kMaxPassSpp) spp_pass = kMaxPassSpp;  // sample-in-pass field of the stream bookkeeping word
+    if (in.stack_form && spp_pass < in.spp) {
+        // passes of equal length (4096 samples in passes of 682 at most would end with one of 4 samples: short streams,
+        // a launch that cannot fill the chip); a pass may be up to a twentieth longer than asked for that - k_pass_cand's
+        // memory does not grow with the pass
+        const uint32_t stretch = spp_pass + spp_pass / 20u;
+        const uint32_t n_eq = (in.spp + stretch - 1u) / stretch;
+        const uint32_t eq = (in.spp + n_eq - 1u) / n_eq;
+        if (eq <= kMaxPassSpp) spp_pass = eq;
+    }
+    // Streams: many more than the 2048 workgroups the chip holds at once, so that the dispatcher keeps every CU busy
+    // until a launch ends, but each still a few launches' worth of work for its workgroup - about 2048 primary rays
+    // per stream and pass (measured on cornell 1024x768: 2048 streams 22.0, 8192 24.3, 16384 24.7, 65536 23.2 G
+    // bounces/s).  A stream owns at most kMaxStreamPixels pixels (their accumulators live in LDS inside k_shade).
+    // (scenes with a BVH stage its nodes into LDS once per workgroup: twice the work per stream; mesh.json 2048 streams
+    // 7.3, 8192 7.6, 16384 7.0)
+    // (candidate scan, four waves per SIMD: 12288 streams 35.8, 16384 35.4, 8192 32.2, 24576 33.7 G bounces/s)
+    // (candidate scan with walks, mesh.json: 24576 streams 19.8, 26624 20.5, 28672 20.1, 30720 20.3, 32768 19.9 G bounces/s)
+    // (k_pass_cand's waves run without levels: a wave's first and last trips - the stack fills, the last rays die - are
+    // the only ones that are not full, so its streams are long: 12 Ki primaries 43.4, 24 Ki 44.3, 48 Ki 43.8.  Fewer, much
+    // longer streams - 2 048 of 384 pixels, two rounds of resident workgroups - lose: 42.0 against 46.4; 4 096: 43.4; 8 192:
+    // 45.1 - workgroups that start together run in step and wait for the same things at the same time)
+    const uint64_t per_stream = in.stack_form ? (uint64_t)(in.per_stream ? in.per_stream : 24576u) : (in.has_bvh ? 4096u : 2048u);
+    uint64_t k_target = (npix * spp_pass + per_stream - 1u) / per_stream;
+    if (k_target < 2048u) k_target = 2048u;
+    if (in.streams) k_target = in.streams;
+    uint32_t m = (uint32_t)((npix + k_target - 1) / k_target);
+    if (m == 0) m = 1;
+    if (m > kMaxStreamPixels) m = kMaxStreamPixels;
+    // k_pass_cand: frames of few samples get more, shorter streams rather than a handful of workgroups per CU slot, each
+    // with hundreds of pixels' accumulators and tables (36 B per pixel) in LDS (1024x768 @128: 12 288 streams of 64
+    // pixels, not 4 096 of 192)
+    if (in.stack_form && !in.streams && m > 64u) m = 64u;
+    // A launch runs its workgroups in rounds of as many as the chip holds (four per CU); a stream's work grows with its m
+    // pixels, so a launch takes about ceil(K / resident) x m: among the m within -15 % / +20 % of the tuned size take the
+    // one for which that is smallest (cornell 1024x768: m = 21 -> 24, 37 450 streams in 36.6 rounds -> 32 768 in 32.0,
+    // 37.3 -> 37.7 G bounces/s).  Not for scenes with walks, whose streams differ too much in length for rounds to show
+    // (mesh.json: 24.0 rounds are slower than 25.6).
+    if (in.cand_scan && !in.has_bvh && !in.streams && in.n_cus != 0u && m >= 8u) {
+        const uint64_t resident = (uint64_t)in.n_cus * 4u;
+        uint32_t best_m = m;
+        uint64_t best_cost = ~0ull;
+        for (uint32_t mm = m - m * 15u / 100u; mm <= m + m / 5u && mm <= (in.stack_form ? 72u : kMaxStreamPixels); ++mm) {
+            const uint64_t kk = (npix + mm - 1u) / mm;
+            const uint64_t cost = ((kk + resident - 1u) / resident) * mm;
+            if (cost < best_cost || (cost == best_cost && (mm > m ? mm - m : m - mm) < (best_m > m ? best_m - m : m - best_m))) {
+                best_cost = cost;
+                best_m = mm;
+            }
+        }
+        m = best_m;
+    }
+    const uint32_t K = (uint32_t)((npix + m - 1) / m);
+    // a primary ray has at most 4 descendants alive at one depth (two refract splits, mod.rs:760); k_pass_cand gives each
+    // of its four waves a quarter of the slice and ceil(n / 4) of the stream's n primaries: 4 * ceil(n / 4) <= n + 3
+    uint64_t cap64 = (4ull * m * spp_pass + 16u + kBlock - 1) / kBlock * kBlock;
+    // k_pass_cand keeps a wave's waiting rays on a stack of at most kWaveStackMax slots (a quarter of the stream's slice
+    // per wave, a power of two of at least 128 slots; a pass whose waves' whole quarters fit a smaller stack gets that)
+    if (in.stack_form) {
+        const uint64_t need_w = (uint64_t)m * spp_pass + 8u;
+        uint64_t cap_w = 128u;
+        const uint64_t stack_max = in.wave_stack ? in.wave_stack : kWaveStackMax;
+        while (cap_w < need_w && cap_w < stack_max) cap_w *= 2u;
+        cap64 = 4u * cap_w;
+        const size_t need = queue_bytes(K, (uint32_t)cap64) + (in.stack_park ? (size_t)K * 4u * kWaveParkBytes : 0u);
+        if (in.stack_budget && need > in.stack_budget && spp_pass > 1u) {
+            // the default pass does not fit the budget: smaller passes have fewer streams or smaller stacks
+            *want_next = npix * (spp_pass / 2u);
+            return kPlanRetry;
+        }
+    }
+    // (slot indices are 32-bit over the whole queue, byte offsets 32-bit inside a stream's slice of cap * 40 bytes)
+    if (cap64 * K > 0xffffffffull / 2 || cap64 * kRayBytes > 0xffffffffull) {
+        if (spp_pass > 1u && in.want_is_default) {  // (a default this large only on a device with > 680 GB)
+            *want_next = in.want / 2;
+            return kPlanRetry;
+        }
+        return kPlanTooLarge;
+    }
+    out.spp_pass = spp_pass;
+    out.m = m;
+    out.K = K;
+    out.cap = (uint32_t)cap64;
+    out.bytes0 = queue_bytes(K, out.cap);
+    out.bytes1 = in.stack_form ? (in.stack_park ? (size_t)K * 4u * kWaveParkBytes : 0u) : out.bytes0;
+    return kPlanOk;
+}
+
 }  // namespace host
 }  // namespace pt

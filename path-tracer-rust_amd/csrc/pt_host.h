@@ -48,6 +48,32 @@ void box_pair_records(const pt_triangle box[12], const float position[3], TriPai
 // validate + flatten (see pt_device.h for the record layouts); false + message on malformed input
 // `cam` only widens the distance bound that sizes the BVH box padding (ray origins include the lens centre)
 bool bvh_refs_fit(uint64_t n_nodes, uint64_t n_pair_records);
+
+// How a wavefront frame is cut into passes and streams (render_wavefront, pt_api.hip): pure arithmetic, tested on the CPU.
+struct PassPlanIn {
+    uint64_t npix = 0;          // pixels of the call (or of its part)
+    uint32_t spp = 0;           // samples per pixel of the frame
+    uint64_t want = 0;          // primary rays per pass that are asked for
+    bool want_is_default = true;  // `want` is the library's choice (it may be halved to fit index ranges)
+    bool stack_form = false;    // k_pass_cand: a stack of waiting rays per wave, passes sized by time
+    bool stack_park = false;    // ... with walks: a parking area per wave in the second container
+    bool cand_scan = false, has_bvh = false;
+    uint64_t streams = 0;       // PT_STREAMS (0: derived)
+    uint32_t per_stream = 0;    // PT_PER_STREAM (0: default)
+    uint32_t wave_stack = 0;    // PT_WAVE_STACK (0: kWaveStackMax)
+    uint32_t n_cus = 0;         // compute units of the device (0: unknown - no whole-rounds nudge)
+    size_t stack_budget = 0;    // stack_form, default pass: bytes the streams' stacks may take (0: unbounded)
+};
+struct PassPlan {
+    uint32_t spp_pass = 0;  // samples of a pixel per pass
+    uint32_t m = 0;         // pixels per stream
+    uint32_t K = 0;         // streams (workgroups per launch)
+    uint32_t cap = 0;       // slots of a stream's slice of a queue container (k_pass_cand: 4 x the waves' stack)
+    size_t bytes0 = 0, bytes1 = 0;  // the two containers
+};
+enum { kPlanOk = 0, kPlanRetry = 1, kPlanTooLarge = 2 };
+// kPlanRetry: the plan does not fit (the stacks' budget, or 32-bit slot indices) - try again with in.want = *want_next
+int plan_pass(const PassPlanIn &in, PassPlan &out, uint64_t *want_next);
 bool flatten_scene(const pt_camera &cam, const pt_object *objs, uint32_t n_objs, const pt_triangle *tris,
                    uint32_t n_tris, FlatScene &out, std::string &err);
 

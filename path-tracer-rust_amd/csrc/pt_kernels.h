@@ -7,10 +7,10 @@
 
 namespace pt {
 
-constexpr uint32_t kBlock = 256;    // 4 waves of 64
 constexpr uint32_t kBlockBvh = 256;  // workgroup of the intersect kernel of scenes with a BVH
-constexpr uint32_t kMaxStreamPixels = 1024;  // pixels owned by one stream (24 KiB of LDS accumulators at most)
 constexpr uint32_t kLevels = 13;    // ray depths 0..11 plus the (always empty) level written by the last shade
+// (kBlock, kMaxStreamPixels, kRayBytes, the wave-stack sizes and queue_bytes: pt_device.h - the pass planner of pt_host.cpp
+// needs them without the HIP headers)
 
 // The ray queue: K stream slices of cap * 40 bytes, each slice three arrays of `cap` slots one after the other -
 //   [od0: float4 origin xyz, direction x][tp: float4 throughput rgb, bookkeeping word (pack_word)][od1: float2 direction yz]
@@ -18,13 +18,7 @@ constexpr uint32_t kLevels = 13;    // ray depths 0..11 plus the (always empty) 
 struct RayQueue {
     char *buf;
 };
-constexpr uint32_t kRayBytes = 40;
-constexpr uint32_t kWaveParkCap = 128;    // parked rays of a wave (k_pass_cand with walks: 63 left over + 64 new at most)
-constexpr uint32_t kWaveParkBytes = kWaveParkCap * (kRayBytes + 8u);  // the ray (40 B) and its key so far (8 B)
-constexpr uint32_t kWaveStackMax = 1024;  // slots of a wave's ray stack (k_pass_cand: a quarter of the stream's slice).  What may
-                                          // ever wait is bounded by phi (k_pass_cand); with 1024 slots a wave that is about to
-                                          // start primaries (fewer than 64 rays waiting, fewer than 64 parked) is never held back
-inline size_t queue_bytes(size_t K, uint32_t cap) { return K * (size_t)cap * kRayBytes; }
+
 
 // one whole pass of a scene without BVH meshes in one launch (see k_pass)
 hipError_t launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const FrameParams &F, const RayQueue &q0,

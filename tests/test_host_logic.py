@@ -256,3 +256,91 @@ def test_flat_filter_sign_rule_needs_well_shaped_triangles(tmp_path):
                            str(src), "-o", exe, "-L", ptlib.PKG, "-lptrace_hip", "-Wl,-rpath," + ptlib.PKG])
     assert subprocess.check_output([exe, "0"]).decode().split() == ["OK", "axis", "2", "sign_exact", "1"]
     assert subprocess.check_output([exe, "1"]).decode().split() == ["OK", "axis", "2", "sign_exact", "0"]
+
+
+PLAN_SRC = r"""
+#include <cstdio>
+#include <cstdlib>
+#include "ptrace.h"
+#include "pt_host.h"
+using namespace pt;
+// argv: npix spp want default(0/1) stack_form stack_park cand_scan has_bvh streams per_stream wave_stack n_cus budget
+// prints the plan after following plan_pass's retries the way render_wavefront does: OK spp_pass m K cap bytes0 bytes1 retries
+int main(int argc, char **argv) {
+    if (argc != 14) return 2;
+    host::PassPlanIn in;
+    in.npix = strtoull(argv[1], 0, 10);
+    in.spp = (uint32_t)strtoul(argv[2], 0, 10);
+    in.want = strtoull(argv[3], 0, 10);
+    in.want_is_default = argv[4][0] == '1';
+    in.stack_form = argv[5][0] == '1';
+    in.stack_park = argv[6][0] == '1';
+    in.cand_scan = argv[7][0] == '1';
+    in.has_bvh = argv[8][0] == '1';
+    in.streams = strtoull(argv[9], 0, 10);
+    in.per_stream = (uint32_t)strtoul(argv[10], 0, 10);
+    in.wave_stack = (uint32_t)strtoul(argv[11], 0, 10);
+    in.n_cus = (uint32_t)strtoul(argv[12], 0, 10);
+    in.stack_budget = (size_t)strtoull(argv[13], 0, 10);
+    host::PassPlan p;
+    int retries = 0;
+    for (;;) {
+        uint64_t next = in.want;
+        const int rc = host::plan_pass(in, p, &next);
+        if (rc == host::kPlanOk) break;
+        if (rc == host::kPlanTooLarge) { printf("TOOLARGE\n"); return 0; }
+        if (next >= in.want || ++retries > 64) { printf("STUCK\n"); return 1; }
+        in.want = next;
+    }
+    printf("OK %u %u %u %u %zu %zu %d\n", p.spp_pass, p.m, p.K, p.cap, p.bytes0, p.bytes1, retries);
+    return 0;
+}
+"""
+
+
+def test_pass_plan(tmp_path):
+    """host::plan_pass - how render_wavefront cuts a frame into passes and streams - on the CPU: the bench frame (six passes of
+    683 samples, stacks of 1024 slots per wave, nothing in the second container), mesh.json (parking areas), a frame of few
+    samples (at most 64 pixels per stream), the memory budget (passes halved until the stacks fit), small stacks on request,
+    tiny passes (smaller stacks), the level-by-level forms (slices of 4 slots per primary ray, two containers), and a pass
+    that 32-bit slot indices cannot hold."""
+    src = tmp_path / "p.cpp"
+    src.write_text(PLAN_SRC)
+    exe = str(tmp_path / "p")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ptlib.PKG, "csrc"), "-I", os.path.join(ptlib.ROOT, "include"),
+                           str(src), "-o", exe, "-L", ptlib.PKG, "-lptrace_hip", "-Wl,-rpath," + ptlib.PKG])
+
+    def plan(npix, spp, want, default=1, stack=1, park=0, cand=1, bvh=0, streams=0, per_stream=0, wave_stack=0, n_cus=256, budget=0):
+        out = subprocess.check_output([exe] + [str(v) for v in (npix, spp, want, default, stack, park, cand, bvh, streams, per_stream,
+                                                                wave_stack, n_cus, budget)]).decode().split()
+        if out[0] != "OK":
+            return out[0]
+        spp_pass, m, K, cap, b0, b1, retries = map(int, out[1:])
+        assert K * m >= npix > (K - 1) * m and 1 <= m <= 1024 and 1 <= spp_pass <= spp and cap % 4 == 0
+        if stack:
+            w = cap // 4
+            assert w & (w - 1) == 0 and 128 <= w <= 1024 and (m * spp_pass + 8 <= w or w == (wave_stack or 1024))
+            assert b0 == K * cap * 40 and b1 == (K * 4 * 128 * 48 if park else 0)
+        else:
+            assert cap >= 4 * m * spp_pass + 16 and cap % 256 == 0 and b0 == b1 == K * cap * 40
+        return spp_pass, m, K, cap, retries
+
+    npix = 1024 * 768
+    spp_pass, m, K, cap, _ = plan(npix, 4096, 512 << 20)
+    assert spp_pass == 683 and cap == 4096 and -(-4096 // spp_pass) == 6 and 4096 - 5 * spp_pass > 600  # six equal passes
+    assert (m, K) == (32, 24576)  # streams of about 24 Ki primaries (36 pixels), nudged to whole rounds of 1024 resident workgroups
+    spp_pass, m, K, cap, _ = plan(npix, 1024, 512 << 20, park=1, bvh=1)  # mesh.json: two passes of 512, no nudge
+    assert spp_pass == 512 and m == -(-npix // -(-npix * 512 // 24576)) and cap == 4096
+    spp_pass, m, K, cap, _ = plan(npix, 128, 512 << 20)  # few samples: one pass, short streams of at most 64 (+ nudge) pixels
+    assert spp_pass == 128 and m <= 72 and K >= 10922
+    spp_pass, m, K, cap, retries = plan(128 * 96, 64, 512 << 20, budget=8 << 20)  # the budget test of the GPU suite
+    assert spp_pass == 1 and retries == 6 and cap == 512
+    spp_pass, m, K, cap, _ = plan(npix, 4096, 512 << 20, wave_stack=512)
+    assert cap == 2048
+    spp_pass, m, K, cap, _ = plan(48 * 32, 8, 512 << 20)  # a tiny frame: 2048 streams of one pixel, 8 + 8 <= 128 slots
+    assert (spp_pass, m, cap) == (8, 1, 512)
+    spp_pass, m, K, cap, _ = plan(npix, 4096, 96 << 20, stack=0)  # level by level: 128 samples per pass, 4 slots per primary
+    assert spp_pass == 128 and cap >= 4 * m * 128
+    assert plan(1 << 20, 32767, 1 << 31, default=0, stack=0) == "TOOLARGE"
+    spp_pass, m, K, cap, retries = plan(1 << 20, 32767, 1 << 31, default=1, stack=0)  # the same as a default: halved until it fits
+    assert retries >= 1 and K * cap <= 0x7fffffff
