@@ -658,7 +658,8 @@ int plan_pass(const PassPlanIn &in, PassPlan &out, uint64_t *want_next) {
     // (k_pass_cand's waves run without levels: a wave's first and last trips - the stack fills, the last rays die - are
     // the only ones that are not full, so its streams are long: 12 Ki primaries 43.4, 24 Ki 44.3, 48 Ki 43.8.  Fewer, much
     // longer streams - 2 048 of 384 pixels, two rounds of resident workgroups - lose: 42.0 against 46.4; 4 096: 43.4; 8 192:
-    // 45.1 - workgroups that start together run in step and wait for the same things at the same time)
+    // 45.1 - same instruction count, but a fifth of the launch with few workgroups left (PMC: busy cycles per bounce 1.97
+    // against 1.64 at fewer wave-cycles): streams are not equally long and two rounds cannot average that out)
     const uint64_t per_stream = in.stack_form ? (uint64_t)(in.per_stream ? in.per_stream : 24576u) : (in.has_bvh ? 4096u : 2048u);
     uint64_t k_target = (npix * spp_pass + per_stream - 1u) / per_stream;
     if (k_target < 2048u) k_target = 2048u;
