@@ -1260,13 +1260,40 @@ __global__ __launch_bounds__(kBlock) void k_scatter_chunks(const float *__restri
 // The refract split (mod.rs:775-786) pushes the transmitted ray on a two-entry stack in registers.
 // One launch = one ROUND: the samples [s_begin, s_end) of every pixel of the call; item = (pixel, part of the round):
 // part k of `n_split` walks the samples s_begin + k*lane_spp ... (< s_end).
-template <bool BVH, bool PROBE>
-__global__ __launch_bounds__(kBlock) void k_mega(DevScene S, FrameParams F, unsigned long long *__restrict__ acc,
+// CAND (scenes without BVH meshes whose candidate records fit LDS): the closest hit by the candidate scan of k_pass_cand
+// (pt_device.h: spheres exactly, conservative filters, exact tests of the (ray, record) candidates in dense batches of the
+// wave, keys) instead of every object and triangle per lane - with every candidate of a trip tested within the trip (the last
+// batch of a trip is partial: a lane's path cannot wait a trip for its hit the way a stream's chunk can).
+#ifndef PT_MEGA_CAND_WAVES
+#define PT_MEGA_CAND_WAVES 4
+#endif
+template <bool BVH, bool PROBE, bool CAND = false>
+__global__ __launch_bounds__(kBlock, CAND ? PT_MEGA_CAND_WAVES : 1) void k_mega(DevScene S, FrameParams F, unsigned long long *__restrict__ acc,
                                                  uint32_t s_begin, uint32_t s_end, uint32_t lane_spp, uint32_t n_split,
                                                  unsigned long long *__restrict__ total_rays) {
     const uint64_t items = (uint64_t)F.npix * n_split;
     unsigned long long rays = 0;
     if (BVH) stage_bvh(S, dyn_lds);
+    CandLds cand{};
+    CandRing ring;
+    ring.head = 0u;
+    ring.count = 0u;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (CAND) {
+        char *wbase = reinterpret_cast<char *>(dyn_lds) + (size_t)(threadIdx.x >> 6) * kCandWaveBytes;
+        cand.ray_a = reinterpret_cast<float4 *>(wbase);
+        cand.keys = reinterpret_cast<unsigned long long *>(wbase + 128u * 16u);
+        cand.ray_b = reinterpret_cast<float2 *>(wbase + 128u * 24u);
+        cand.queue = reinterpret_cast<uint16_t *>(wbase + 128u * 32u);
+        char *sbase = reinterpret_cast<char *>(dyn_lds) + intersect_cand_lds_bytes();
+        cand.staged = reinterpret_cast<const CandPairRec *>(sbase);
+        cand.surf = S.surf;
+        const uint4 *src = reinterpret_cast<const uint4 *>(S.cand_pairs);
+        uint4 *dst = reinterpret_cast<uint4 *>(sbase);
+        const uint32_t n_rows = S.n_cand_pairs * (uint32_t)(sizeof(CandPairRec) / 16u);
+        for (uint32_t k = threadIdx.x; k < n_rows; k += kBlock) dst[k] = src[k];
+        __syncthreads();
+    }
     for (uint64_t first = (uint64_t)blockIdx.x * kBlock; first < items; first += (uint64_t)gridDim.x * kBlock) {
         const uint64_t item = first + threadIdx.x;
         const bool lane_valid = item < items;
@@ -1302,8 +1329,24 @@ __global__ __launch_bounds__(kBlock) void k_mega(DevScene S, FrameParams F, unsi
                 }
             }
             if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+            HitRec h;
+            h.t = 0.0f;
+            h.id = -1;
+            if (CAND) {  // every lane of the wave takes part; the lanes without a ray have no candidates
+                cand.ray_a[lane] = make_float4(cur.o.x, cur.o.y, cur.o.z, cur.d.x);
+                cand.ray_b[lane] = make_float2(cur.d.y, cur.d.z);
+                float bound;
+                const unsigned long long key0 = cand_spheres(S, cur.o, cur.d, &bound);
+                cand.keys[lane] = active ? key0 : kKeyMiss;
+                cand_filter_and_drain<true>(S, cand, ring, lane, 0u, active, cur.o, cur.d, bound);
+                if (ring.count != 0u) cand_batch<true>(S, cand, ring, lane, ring.count);
+                const unsigned long long key = load_key(&cand.keys[lane]);
+                const uint32_t rank = (uint32_t)key;
+                h.t = __uint_as_float((uint32_t)(key >> 32));
+                h.id = rank != 0xffffffffu ? (int32_t)S.rank_id[rank] : -1;
+            }
             if (active) {
-                const HitRec h = intersect_scene_dev<BVH>(S, cur.o, cur.d, dyn_lds);
+                if (!CAND) h = intersect_scene_dev<BVH>(S, cur.o, cur.d, dyn_lds);
                 ++rays;
                 if (h.id < 0) {
                     active = false;
@@ -1702,6 +1745,15 @@ void launch_resolve(hipStream_t st, const unsigned long long *acc, float *out, u
 }
 void launch_mega(hipStream_t st, uint32_t grid, const DevScene &S, const FrameParams &F, unsigned long long *acc,
                  uint32_t s_begin, uint32_t s_end, uint32_t lane_spp, uint32_t n_split, unsigned long long *total_rays) {
+    const size_t rec = (size_t)S.n_cand_pairs * sizeof(CandPairRec);
+    if (S.n_bvh_nodes == 0u && S.cand_scan && intersect_cand_lds_bytes() + rec <= 40u * 1024u) {  // the candidate scan
+        const size_t lds_c = intersect_cand_lds_bytes() + rec;
+        if (F.probe)
+            hipLaunchKernelGGL((k_mega<false, true, true>), dim3(grid), dim3(kBlock), lds_c, st, S, F, acc, s_begin, s_end, lane_spp, n_split, total_rays);
+        else
+            hipLaunchKernelGGL((k_mega<false, false, true>), dim3(grid), dim3(kBlock), lds_c, st, S, F, acc, s_begin, s_end, lane_spp, n_split, total_rays);
+        return;
+    }
     const size_t lds = S.n_bvh_nodes != 0u ? bvh_lds_bytes(S, kBlock) : 0u;
     if (S.n_bvh_nodes != 0u && F.probe)
         hipLaunchKernelGGL((k_mega<true, true>), dim3(grid), dim3(kBlock), lds, st, S, F, acc, s_begin, s_end, lane_spp, n_split, total_rays);
