@@ -1577,7 +1577,8 @@ __device__ __forceinline__ bool bvh_wants(const DevScene &S, vec3 o, vec3 d, flo
 //    intersect_scene's strict '<' over the whole visiting sequence (mod.rs:598,649), no tie needs a second look.
 template <class NodePtr>
 __device__ __forceinline__ unsigned long long walk_deferred_keys(const DevScene &S, NodePtr nodes, vec3 o, vec3 d, const WalkQueue &Q,
-                                                                 unsigned long long key, unsigned long long *wave_keys) {
+                                                                 unsigned long long key, unsigned long long *wave_keys,
+                                                                 bool want = true) {  // want: this lane's ray may walk at all
     for (uint32_t q = 0; q < S.n_bvh_meshes; ++q) {
         PT_PHASE(kPhWalkGate);
         const BvhMeshRec bm = ld_uniform(S.bvh_meshes + q);
@@ -1585,7 +1586,7 @@ __device__ __forceinline__ unsigned long long walk_deferred_keys(const DevScene 
         const float b = dot(op, d);
         const float det = (b * b - dot(op, op)) + bm.rr;
         const float sq = f_sqrt(det);
-        const bool pass = !(det < 0.0f) && ((b - sq) >= 1e-4f || (b + sq) >= 1e-4f);
+        const bool pass = want && !(det < 0.0f) && ((b - sq) >= 1e-4f || (b + sq) >= 1e-4f);
         if (__builtin_amdgcn_ballot_w64(pass) == 0ull) continue;
         float mt = __builtin_inff();
         int32_t mid = -1;

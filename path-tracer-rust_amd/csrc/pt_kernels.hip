@@ -1273,12 +1273,26 @@ __global__ __launch_bounds__(kBlock, CAND ? PT_MEGA_CAND_WAVES : 1) void k_mega(
                                                  unsigned long long *__restrict__ total_rays) {
     const uint64_t items = (uint64_t)F.npix * n_split;
     unsigned long long rays = 0;
-    if (BVH) stage_bvh(S, dyn_lds);
+    if (BVH && !CAND) stage_bvh(S, dyn_lds);
     CandLds cand{};
     CandRing ring;
     ring.head = 0u;
     ring.count = 0u;
     const uint32_t lane = threadIdx.x & 63u;
+    // CAND with BVH meshes: a lane whose ray may hit one (bvh_wants) walks it in the same trip - the wave's walking rays
+    // share one queue of box tests (bvh_closest_queue), a handful per trip.  LDS after the candidate areas and the staged
+    // records: [per wave: walk queue][per wave: u64 key x 64]
+    WalkQueue wq{};
+    unsigned long long *walk_keys = nullptr;
+    if (CAND && BVH) {
+        char *wl = reinterpret_cast<char *>(dyn_lds) + intersect_cand_lds_bytes() + (((size_t)S.n_cand_pairs * sizeof(CandPairRec) + 15) & ~(size_t)15);
+        char *qb = wl + (size_t)(threadIdx.x >> 6) * pass_cand_queue_bytes(S);
+        wq.redo = reinterpret_cast<uint32_t *>(qb);
+        wq.ent = reinterpret_cast<uint2 *>(qb + kWalkQueueHeader);
+        wq.cap = (uint32_t)((pass_cand_queue_bytes(S) - kWalkQueueHeader) / 8u);
+        if (S.walk_queue_cap >= 128u && S.walk_queue_cap < wq.cap) wq.cap = S.walk_queue_cap;
+        walk_keys = reinterpret_cast<unsigned long long *>(wl + pass_cand_queues_bytes(S) + (size_t)(threadIdx.x >> 6) * kCandWalkKeyBytes);
+    }
     if (CAND) {
         char *wbase = reinterpret_cast<char *>(dyn_lds) + (size_t)(threadIdx.x >> 6) * kCandWaveBytes;
         cand.ray_a = reinterpret_cast<float4 *>(wbase);
@@ -1340,7 +1354,12 @@ __global__ __launch_bounds__(kBlock, CAND ? PT_MEGA_CAND_WAVES : 1) void k_mega(
                 cand.keys[lane] = active ? key0 : kKeyMiss;
                 cand_filter_and_drain<true>(S, cand, ring, lane, 0u, active, cur.o, cur.d, bound);
                 if (ring.count != 0u) cand_batch<true>(S, cand, ring, lane, ring.count);
-                const unsigned long long key = load_key(&cand.keys[lane]);
+                unsigned long long key = load_key(&cand.keys[lane]);
+                if (BVH) {
+                    const bool want = active && bvh_wants(S, cur.o, cur.d, __uint_as_float((uint32_t)(key >> 32)));
+                    if (__builtin_amdgcn_ballot_w64(want) != 0ull)  // wave-uniform
+                        key = walk_deferred_keys(S, S.bvh_nodes, cur.o, cur.d, wq, key, walk_keys, want);
+                }
                 const uint32_t rank = (uint32_t)key;
                 h.t = __uint_as_float((uint32_t)(key >> 32));
                 h.id = rank != 0xffffffffu ? (int32_t)S.rank_id[rank] : -1;
@@ -1745,13 +1764,20 @@ void launch_resolve(hipStream_t st, const unsigned long long *acc, float *out, u
 }
 void launch_mega(hipStream_t st, uint32_t grid, const DevScene &S, const FrameParams &F, unsigned long long *acc,
                  uint32_t s_begin, uint32_t s_end, uint32_t lane_spp, uint32_t n_split, unsigned long long *total_rays) {
-    const size_t rec = (size_t)S.n_cand_pairs * sizeof(CandPairRec);
-    if (S.n_bvh_nodes == 0u && S.cand_scan && intersect_cand_lds_bytes() + rec <= 40u * 1024u) {  // the candidate scan
-        const size_t lds_c = intersect_cand_lds_bytes() + rec;
-        if (F.probe)
-            hipLaunchKernelGGL((k_mega<false, true, true>), dim3(grid), dim3(kBlock), lds_c, st, S, F, acc, s_begin, s_end, lane_spp, n_split, total_rays);
+    const size_t rec = ((size_t)S.n_cand_pairs * sizeof(CandPairRec) + 15) & ~(size_t)15;
+    DevScene S2 = S;
+    S2.bvh_in_lds &= ~5u;  // (the candidate forms read the nodes from global memory, with full-size walk queues)
+    const size_t walk = S.n_bvh_nodes != 0u ? pass_cand_queues_bytes(S2) + (size_t)(kBlock / 64u) * kCandWalkKeyBytes : 0u;
+    if (S.cand_scan && intersect_cand_lds_bytes() + rec + walk <= 40u * 1024u) {  // the candidate scan
+        const size_t lds_c = intersect_cand_lds_bytes() + rec + walk;
+        if (S.n_bvh_nodes != 0u && F.probe)
+            hipLaunchKernelGGL((k_mega<true, true, true>), dim3(grid), dim3(kBlock), lds_c, st, S2, F, acc, s_begin, s_end, lane_spp, n_split, total_rays);
+        else if (S.n_bvh_nodes != 0u)
+            hipLaunchKernelGGL((k_mega<true, false, true>), dim3(grid), dim3(kBlock), lds_c, st, S2, F, acc, s_begin, s_end, lane_spp, n_split, total_rays);
+        else if (F.probe)
+            hipLaunchKernelGGL((k_mega<false, true, true>), dim3(grid), dim3(kBlock), lds_c, st, S2, F, acc, s_begin, s_end, lane_spp, n_split, total_rays);
         else
-            hipLaunchKernelGGL((k_mega<false, false, true>), dim3(grid), dim3(kBlock), lds_c, st, S, F, acc, s_begin, s_end, lane_spp, n_split, total_rays);
+            hipLaunchKernelGGL((k_mega<false, false, true>), dim3(grid), dim3(kBlock), lds_c, st, S2, F, acc, s_begin, s_end, lane_spp, n_split, total_rays);
         return;
     }
     const size_t lds = S.n_bvh_nodes != 0u ? bvh_lds_bytes(S, kBlock) : 0u;
