@@ -302,8 +302,8 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
     // @4096 spp 32 Mi 35.7, 48 Mi 35.7, 64 Mi 36.2, 96 Mi 36.4 G bounces/s (a launch ends with its slowest streams).
     // k_pass_cand (`stack_form`) keeps a wave's waiting rays on a stack of at most kWaveStackMax slots whatever the pass holds:
     // its passes are sized by TIME - 512 Mi primary rays, about 0.1 s between two looks at the cancel flag (the reference
-    // polls it every 100 ms, mod.rs:947-958) - and its memory is the streams' (K x 4 waves x stack x 40 B: 10.7 GB for 32 Ki
-    // streams at most; small passes need less: 4 x pow2(primaries per wave) slots per stream).
+    // polls it every 100 ms, mod.rs:947-958) - and its memory is the streams' (K x 4 waves x stack x 40 B: 4.0 GB for the 24 576
+    // streams of the bench frame's pass; small passes need less: 4 x pow2(primaries per wave) slots per stream).
     // The default is what the DEVICE can give: 85 % of the free memory (plus what this context's queues hold already),
     // divided by the contexts that share the device in this call (PT_FLAG_PIPELINES, ranks of pt_render_multi on one GPU),
     // or pt_ctx_set_memory_budget's figure - at 352 B per primary ray for the level-by-level forms (queues + hit records of
