@@ -45,9 +45,11 @@ void set_error(const std::string &m);  // pt_api.hip
 extern __shared__ uint4 dyn_lds[];
 
 constexpr uint32_t kDeferCap = 128;  // k_pass: deferred glass hits per wave (63 left over + 64 new at most)
-// k_pass LDS: [u64 acc: 3*m][4 x u32: tail counters][u32 pixel index, column, row: 3*m][pad to 16][float4 deferred hits: waves x 3 x kDeferCap]
+// k_pass LDS: [u64 acc: 3*m][kPassTailWords x u32: counters, camera][u32 pixel index, column, row: 3*m][pad to 16][float4 deferred hits: waves x 3 x kDeferCap]
+// the words between the accumulators and the pixel tables: [0..3] counters, [4..17] the camera for k_pass_cand's primary rays
+constexpr uint32_t kPassTailWords = 20;
 __host__ __device__ constexpr size_t pass_lds_defer_offset(uint32_t m) {
-    return ((size_t)3 * m * sizeof(unsigned long long) + 16 + (size_t)3 * m * sizeof(uint32_t) + 15) & ~(size_t)15;
+    return ((size_t)3 * m * sizeof(unsigned long long) + kPassTailWords * 4u + (size_t)3 * m * sizeof(uint32_t) + 15) & ~(size_t)15;
 }
 
 // k_pass_cand LDS: [accumulators, tails, pixel indices as k_pass][per wave: float4 ray_a [128] | u64 key [128] |
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, R
     if (tid == 0) s_tail_p[0] = s_tail_p[1] = 0u;  // appends of level d are counted in s_tail_p[d & 1]
     // framebuffer index (= RNG key) of each of the stream's pixels: the interleaved partition of a multi-GPU call
     // makes it a division per lookup, and it is needed once per bounce
-    uint32_t *lds_pix = s_tail_p + 4;
+    uint32_t *lds_pix = s_tail_p + kPassTailWords;
     for (uint32_t j = tid; j < mb; j += kBlock) lds_pix[j] = global_pixel(F, stream_pixel(F.n_streams, b, j));
     ShadeParams P;
     P.idx_begin = F.idx_begin;
@@ -638,9 +640,18 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
 #endif
     for (uint32_t k = tid; k < 3u * m; k += kBlock) lds_acc[k] = 0ull;
     if (tid == 0) s_tail_p[0] = s_tail_p[1] = 0u;  // (here: the workgroup's ray count, u64)
+    // The camera in LDS: a primary trip (one in nine) reads it from there.  As fields of FrameParams it was a sixteen-register
+    // tuple that the register allocator parked in VGPR lanes for the length of the loop and fetched back with 16 v_readlane per
+    // use (SGPRs are what this kernel is shortest of): 46.6 -> 47.3 G bounces/s on cornell.
+    if (tid == 0) {
+        float *cw = reinterpret_cast<float *>(s_tail_p + 4);
+        cw[0] = F.lens_x, cw[1] = F.lens_y, cw[2] = F.lens_z, cw[3] = F.cam_px, cw[4] = F.cam_py, cw[5] = F.cam_pz;
+        cw[6] = F.su_x, cw[7] = F.su_y, cw[8] = F.su_z, cw[9] = F.sv_x, cw[10] = F.sv_y, cw[11] = F.sv_z;
+        s_tail_p[16] = F.width, s_tail_p[17] = F.height;
+    }
     // per stream pixel: framebuffer index (the RNG counter), and its column and row from the bottom (render_pixel's x, y,
     // mod.rs:805-806): two divisions here instead of two per primary ray
-    uint32_t *lds_pix = s_tail_p + 4;
+    uint32_t *lds_pix = s_tail_p + kPassTailWords;
     uint32_t *lds_px = lds_pix + m, *lds_py = lds_px + m;
     for (uint32_t j = tid; j < mb; j += kBlock) {
         const uint32_t pix = global_pixel(F, stream_pixel(F.n_streams, b, j));
@@ -888,7 +899,16 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
                 PT_PHASE(kPhPrimary);
                 if (cur_valid) {
                     const uint32_t pj = gen_pj, sj = gen_sj;
-                    in = PROBE ? primary_ray<PROBE>(F, lds_pix[pj], s0 + sj) : primary_ray_at(F, lds_pix[pj], lds_px[pj], lds_py[pj], s0 + sj);
+                    FrameParams Fl;  // (the fields primary_ray_at reads)
+                    {
+                        const float4 c0 = *reinterpret_cast<const float4 *>(s_tail_p + 4), c1 = *reinterpret_cast<const float4 *>(s_tail_p + 8),
+                                     c2 = *reinterpret_cast<const float4 *>(s_tail_p + 12);
+                        Fl.lens_x = c0.x, Fl.lens_y = c0.y, Fl.lens_z = c0.z, Fl.cam_px = c0.w, Fl.cam_py = c1.x, Fl.cam_pz = c1.y;
+                        Fl.su_x = c1.z, Fl.su_y = c1.w, Fl.su_z = c2.x, Fl.sv_x = c2.y, Fl.sv_y = c2.z, Fl.sv_z = c2.w;
+                        Fl.width = s_tail_p[16], Fl.height = s_tail_p[17];
+                        Fl.seed_lo = P.seed_lo, Fl.seed_hi = P.seed_hi;
+                    }
+                    in = PROBE ? primary_ray<PROBE>(F, lds_pix[pj], s0 + sj) : primary_ray_at(Fl, lds_pix[pj], lds_px[pj], lds_py[pj], s0 + sj);
                     word = pack_word(pj, sj, PROBE ? F.depth0 : 0u, 1u);
                 }
                 gen_pj += step_r;
@@ -1067,7 +1087,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_bvh(DevScene S, FrameParams 
     if (mb == 0u) return;
     for (uint32_t k = tid; k < 3u * m; k += kBlock) lds_acc[k] = 0ull;
     if (tid == 0) s_tail_p[0] = s_tail_p[1] = 0u;
-    uint32_t *lds_pix = s_tail_p + 4;
+    uint32_t *lds_pix = s_tail_p + kPassTailWords;
     for (uint32_t j = tid; j < mb; j += kBlock) lds_pix[j] = global_pixel(F, stream_pixel(F.n_streams, b, j));
     // traversal stacks (one column per thread), then this wave's parking area: u32 ray index | f32 t | i32 id
     uint4 *const stacks = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(dyn_lds) + pass_bvh_stack_offset(m));
