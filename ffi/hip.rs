@@ -1,4 +1,4 @@
-//! src/render/hip.rs — binding of libptrace_hip.so (include/ptrace.h, ABI 4) for filippo-orru/path-tracer-rust.
+//! src/render/hip.rs — binding of libptrace_hip.so (include/ptrace.h, ABI 5) for filippo-orru/path-tracer-rust.
 //!
 //! NOT COMPILED HERE: the build image has no Rust toolchain.  This is the file a maintainer adds as `mod hip;` in
 //! `src/render/mod.rs` (a child module of `render`, so it may read the private fields of `Mesh` and

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 4
+#define PT_ABI_VERSION 5
 
 /* status codes (reference behaviour: unwrap() panics, mod.rs:96,309,1032,1042,1093) */
 #define PT_OK 0
@@ -148,6 +148,9 @@ const char *pt_version(void);
 /* the back-end (-mllvm) switches the library was built with: the Makefile probes each against the compiler and drops the
  * ones it rejects (they only steer instruction placement: same images with any subset) */
 const char *pt_build_flags(void);
+/* the first 16 hex digits of sha256 over the device assembly the library's kernels were built from (Makefile: pt_kernels.s of
+ * the same compile): the _traffic.json files under profiles/ name the hash of the library they were measured on, bench.py compares */
+const char *pt_kernel_isa_hash(void);
 const char *pt_last_error(void);
 int pt_abi_version(void);
 int pt_device_count(void);
@@ -194,7 +197,8 @@ int pt_bvh_refs_fit(uint64_t n_bvh_nodes, uint64_t n_pair_records);
  * for the 24 576 streams of a 1024x768 pass of 683 samples; small passes need less); the level-by-level forms (PT_FLAG_SEPARATE_KERNELS,
  * PT_FLAG_NO_BVH, PT_CAND_SCAN=0) hold rays_per_pass primary rays at 352 B each, 36 GB at their default.  A pass that does
  * not fit is halved until it does (a failed allocation does the same), which changes how the samples are batched and
- * nothing in the image. */
+ * nothing in the image.  A figure set here also bounds an explicit pt_config.rays_per_pass (the budget wins); without one
+ * an explicit rays_per_pass is taken as given and only a failed allocation halves it. */
 int pt_ctx_set_memory_budget(pt_ctx *ctx, size_t bytes);
 
 /* Enable HIP-event timing of every launch of the dominant kernel (fills pt_stats.ms_intersect). */
@@ -268,6 +272,23 @@ int pt_ctx_numerics_probe(pt_ctx *ctx, const float *in, uint32_t n, float *out_s
  * out[0], out[1] = inputs whose results differ in bits (NaN == NaN) - both must be 0; out[2], out[3] = inputs compared.
  * About a second of GPU time. */
 int pt_ctx_numerics_sweep(pt_ctx *ctx, uint64_t out[4]);
+
+/* Diagnostics, exhaustive: the device's sincos_f32 - the one transcendental of the path, cos / sin of r1 = 2 pi rand01()
+ * in the diffuse bounce (mod.rs:691,703) - on ALL 2^24 arguments that expression can take (rand01() = k * 2^-24, rand
+ * 0.8.5's f32 mapping) against the host instantiation of the same source (pt_host_sincos, which tests/test_abi.py holds to
+ * the platform libm on the same arguments).  out[0] = arguments whose sine or cosine differs in bits (must be 0),
+ * out[1] = arguments compared (2^24).  Uploads two 64 MB tables; well under a second of GPU time. */
+int pt_ctx_sincos_sweep(pt_ctx *ctx, uint64_t out[2]);
+
+/* Diagnostics: the per-sample part of render_pixel (mod.rs:805-843) - y = H-1 - idx/W, x = idx%W, the (s%2, (s/2)%2)
+ * sub-pixel, the tent filter of two rand01() draws, sx / sy, sensor_pos = (position + su*sx) + sv*sy, direction =
+ * (lens_center - sensor_pos).normalize(), origin = lens_center - ON THE DEVICE, through the functions the frame kernels
+ * call, for n (framebuffer index, sample) pairs of a width x height frame with the context's camera; the two draws are
+ * words 0 and 1 of the RNG block (seed; pixel, sample, tag 0).  form 0: as k_generate / k_mega / k_pass make it (column and
+ * row by division), form 1: as k_pass_cand makes it (column and row handed in).  The oracle's pto_primary_ray is the
+ * counterpart; tests/kats_camera.py holds both to an independent restatement, bit for bit.  Host arrays: o, d = n*3. */
+int pt_ctx_primary_rays(pt_ctx *ctx, uint32_t width, uint32_t height, uint64_t seed, const uint32_t *pixel,
+                        const uint32_t *sample, uint32_t n, uint32_t form, float *o, float *d);
 
 /* The host instantiation of the shared numerics header's sincos (the same source the kernels compile). */
 void pt_host_sincos(float y, float *s, float *c);

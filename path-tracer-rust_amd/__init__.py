@@ -67,6 +67,7 @@ def lib():
     L = C.CDLL(LIB_PATH)
     L.pt_version.restype = C.c_char_p
     L.pt_build_flags.restype = C.c_char_p
+    L.pt_kernel_isa_hash.restype = C.c_char_p
     L.pt_last_error.restype = C.c_char_p
     L.pt_device_count.restype = C.c_int
     L.pt_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
@@ -223,6 +224,20 @@ class Comm:
 def build_flags():
     """The back-end (-mllvm) switches the library was built with (the Makefile drops the ones the compiler rejects)."""
     return lib().pt_build_flags().decode()
+
+
+def kernel_isa_hash():
+    """Hash of the device assembly the loaded library's kernels were built from (profiles name the one they measured)."""
+    return lib().pt_kernel_isa_hash().decode()
+
+
+# the -mllvm set the Makefile asks for (instruction placement only; worth 3.5 % on mesh.json): a library built without some of
+# them - its compiler did not know them - still renders the same images
+BUILD_FLAGS_WANTED = ("-enable-post-misched=0", "-amdgpu-sched-strategy=max-ilp", "-disable-machine-licm", "-disable-machine-sink")
+
+
+def build_flags_complete():
+    return all(f in build_flags() for f in BUILD_FLAGS_WANTED)
 
 
 def image_hash(frame):

@@ -333,6 +333,17 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
         if (stack_form) stack_budget = avail;
         if (c->mem_share > 1u && want > dflt / c->mem_share) want = dflt / c->mem_share;  // (co-resident contexts also share the chip)
         if (want < npix) want = npix;  // one sample per pixel and pass at least
+    } else if (c->mem_budget) {
+        // an explicit pass size under an explicit budget (pt_ctx_set_memory_budget): the budget wins - the pass is cut to what
+        // it allows (level-by-level forms: 352 B per primary ray; k_pass_cand: its streams' stacks, plan_pass retries with
+        // smaller passes).  Without a budget an explicit size is taken as given and only a failed allocation halves it.
+        if (!stack_form) {
+            const uint64_t fit = c->mem_budget / 352u;
+            if (fit < want) want = fit;
+        } else {
+            stack_budget = c->mem_budget;
+        }
+        if (want < npix) want = npix;
     }
     uint32_t spp_pass = 0, m = 0, K = 0, cap = 0;
     for (;;) {
@@ -1466,6 +1477,96 @@ int pt_ctx_numerics_sweep(pt_ctx *c, uint64_t out[4]) {
         return PT_ERR_HIP;
     }
     for (int i = 0; i < 4; ++i) out[i] = h[i];
+    return PT_OK;
+}
+
+int pt_ctx_sincos_sweep(pt_ctx *c, uint64_t out[2]) {
+    if (!c || !out) {
+        set_error("NULL argument");
+        return PT_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    // the host instantiation of the shared numerics header on the 2^24 arguments shade_surface can form (mod.rs:691,703)
+    const uint32_t n = 1u << 24;
+    std::vector<uint32_t> hs(n), hc(n);
+    for (uint32_t k = 0; k < n; ++k) {
+        const float r1 = (2.0f * 3.141592653589793f) * unit_f32(k << 8);
+        float s, co;
+        sincos_f32(r1, &s, &co);
+        memcpy(&hs[k], &s, 4);
+        memcpy(&hc[k], &co, 4);
+    }
+    DevBuf<uint32_t> ds, dc;
+    DevBuf<unsigned long long> d;
+    int rc;
+    if ((rc = ds.ensure(n)) || (rc = dc.ensure(n)) || (rc = d.ensure(2))) return rc;
+    hipError_t e = hipMemcpy(ds.p, hs.data(), (size_t)n * 4u, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dc.p, hc.data(), (size_t)n * 4u, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemsetAsync(d.p, 0, 2 * sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) {
+        launch_sincos_sweep(c->stream, ds.p, dc.p, d.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    unsigned long long h[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpy(h, d.p, sizeof h, hipMemcpyDeviceToHost);
+    ds.release();
+    dc.release();
+    d.release();
+    if (e != hipSuccess) {
+        set_error(std::string("sincos sweep: ") + hipGetErrorString(e));
+        return PT_ERR_HIP;
+    }
+    out[0] = h[0];
+    out[1] = h[1];
+    return PT_OK;
+}
+
+int pt_ctx_primary_rays(pt_ctx *c, uint32_t width, uint32_t height, uint64_t seed, const uint32_t *pixel, const uint32_t *sample,
+                        uint32_t n, uint32_t form, float *o, float *d) {
+    if (!c || !pixel || !sample || !o || !d || n == 0 || form > 1u) {
+        set_error("NULL argument, n == 0 or an unknown form");
+        return PT_ERR_INVALID;
+    }
+    if (!c->has_scene) {
+        set_error("no scene (the camera comes with it): call pt_ctx_set_scene first");
+        return PT_ERR_INVALID;
+    }
+    pt_config cfg{};
+    cfg.width = width;
+    cfg.height = height;
+    cfg.spp = 1;
+    cfg.seed = seed;
+    uint32_t ib = 0, ie = 0;
+    int rc = check_cfg(&cfg, &ib, &ie);
+    if (rc) return rc;
+    for (uint32_t i = 0; i < n; ++i)
+        if (pixel[i] >= (uint64_t)width * height || sample[i] >= (1u << 24)) {
+            set_error("pixel index outside the frame or sample >= 2^24");
+            return PT_ERR_INVALID;
+        }
+    HIP_TRY(hipSetDevice(c->device));
+    const FrameParams F = make_frame(c, &cfg, ib, ie);
+    DevBuf<uint32_t> dp, dsm;
+    DevBuf<float> d_o, d_d;
+    if ((rc = dp.ensure(n)) || (rc = dsm.ensure(n)) || (rc = d_o.ensure(3 * (size_t)n)) || (rc = d_d.ensure(3 * (size_t)n))) return rc;
+    hipError_t e = hipMemcpy(dp.p, pixel, (size_t)n * 4u, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dsm.p, sample, (size_t)n * 4u, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        launch_primary_rays(c->stream, F, dp.p, dsm.p, n, form, d_o.p, d_d.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(o, d_o.p, 3 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(d, d_d.p, 3 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
+    dp.release();
+    dsm.release();
+    d_o.release();
+    d_d.release();
+    if (e != hipSuccess) {
+        set_error(std::string("primary rays: ") + hipGetErrorString(e));
+        return PT_ERR_HIP;
+    }
     return PT_OK;
 }
 

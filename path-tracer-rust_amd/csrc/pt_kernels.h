@@ -49,6 +49,11 @@ void launch_query(hipStream_t st, const DevScene &S, const float *o, const float
 void launch_bounds(hipStream_t st, const DevScene &S, const TriPairRec *boxes, uint32_t mode, uint32_t object, const float *o,
                    const float *d, uint32_t n, int32_t *hit, float *t, float *x, float *nrm, int32_t *object_id);
 void launch_numerics_sweep(hipStream_t st, unsigned long long *out4);
+// sincos_f32 on all 2^24 reachable arguments against host tables (bit patterns); out2 = {mismatches, compared}
+void launch_sincos_sweep(hipStream_t st, const uint32_t *want_sin, const uint32_t *want_cos, unsigned long long *out2);
+// render_pixel's per-sample ray for n (framebuffer index, sample) pairs; form 0: primary_ray, 1: primary_ray_at
+void launch_primary_rays(hipStream_t st, const FrameParams &F, const uint32_t *pixel, const uint32_t *sample, uint32_t n, uint32_t form,
+                         float *o, float *d);
 void launch_numerics(hipStream_t st, const float *in, uint32_t n, float *out_sin, float *out_cos, float *out_sqrt,
                      float *out_rcp, uint32_t *out_philox);
 

@@ -48,9 +48,14 @@ constexpr uint32_t kDeferCap = 128;  // k_pass: deferred glass hits per wave (63
 // k_pass LDS: [u64 acc: 3*m][kPassTailWords x u32: counters, camera][u32 pixel index, column, row: 3*m][pad to 16][float4 deferred hits: waves x 3 x kDeferCap]
 // the words between the accumulators and the pixel tables: [0..3] counters, [4..17] the camera for k_pass_cand's primary rays
 constexpr uint32_t kPassTailWords = 20;
+// u64 slots of the accumulator area: 3*m rounded up to even, so that the words behind it start on a 16-byte boundary whatever m
+// is (k_pass_cand reads the camera from there as three float4: with an odd m - small frames have m = 1 - those were
+// 8-byte-aligned ds_read_b128, which only the hardware's unaligned-DS mode forgives)
+__host__ __device__ constexpr uint32_t pass_acc_slots(uint32_t m) { return (3u * m + 1u) & ~1u; }
 __host__ __device__ constexpr size_t pass_lds_defer_offset(uint32_t m) {
-    return ((size_t)3 * m * sizeof(unsigned long long) + kPassTailWords * 4u + (size_t)3 * m * sizeof(uint32_t) + 15) & ~(size_t)15;
+    return ((size_t)pass_acc_slots(m) * sizeof(unsigned long long) + kPassTailWords * 4u + (size_t)3 * m * sizeof(uint32_t) + 15) & ~(size_t)15;
 }
+static_assert(pass_acc_slots(1) == 4u && pass_acc_slots(2) == 6u && (pass_acc_slots(7) * 8u) % 16u == 0u, "tails are 16-byte aligned");
 
 // k_pass_cand LDS: [accumulators, tails, pixel indices as k_pass][per wave: float4 ray_a [128] | u64 key [128] |
 // float2 ray_b [128] | u16 ring [kCandQueueCap]][staged candidate records]
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, ShadeParams F, Ray
                                                   uint32_t *__restrict__ flags, uint32_t m) {
     // dynamic LDS: [u64 acc: 3*m][u32 tail]
     unsigned long long *lds_acc = reinterpret_cast<unsigned long long *>(dyn_lds);
-    uint32_t *s_tail_p = reinterpret_cast<uint32_t *>(lds_acc + 3u * m);
+    uint32_t *s_tail_p = reinterpret_cast<uint32_t *>(lds_acc + pass_acc_slots(m));
 #define s_tail (*s_tail_p)
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
     const uint32_t n = cnt_in[b];
@@ -421,7 +426,7 @@ __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, R
                                                  unsigned long long *__restrict__ blk_rays,
                                                  uint32_t *__restrict__ flags) {
     unsigned long long *lds_acc = reinterpret_cast<unsigned long long *>(dyn_lds);
-    uint32_t *s_tail_p = reinterpret_cast<uint32_t *>(lds_acc + 3u * m);
+    uint32_t *s_tail_p = reinterpret_cast<uint32_t *>(lds_acc + pass_acc_slots(m));
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
     const uint32_t mb = stream_pixel_count(F.npix, F.n_streams, b);  // <= m
     if (mb == 0u) return;
@@ -630,7 +635,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
                                                          unsigned long long *__restrict__ blk_rays,
                                                          uint32_t *__restrict__ flags) {
     unsigned long long *lds_acc = reinterpret_cast<unsigned long long *>(dyn_lds);
-    uint32_t *s_tail_p = reinterpret_cast<uint32_t *>(lds_acc + 3u * m);
+    uint32_t *s_tail_p = reinterpret_cast<uint32_t *>(lds_acc + pass_acc_slots(m));
     const uint32_t b = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
     const uint32_t mb = stream_pixel_count(F.npix, F.n_streams, b);  // <= m
     if (mb == 0u) return;
@@ -1081,7 +1086,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_bvh(DevScene S, FrameParams 
                                                         unsigned long long *__restrict__ blk_rays,
                                                         uint32_t *__restrict__ flags) {
     unsigned long long *lds_acc = reinterpret_cast<unsigned long long *>(dyn_lds);
-    uint32_t *s_tail_p = reinterpret_cast<uint32_t *>(lds_acc + 3u * m);
+    uint32_t *s_tail_p = reinterpret_cast<uint32_t *>(lds_acc + pass_acc_slots(m));
     const uint32_t b = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
     const uint32_t mb = stream_pixel_count(F.npix, F.n_streams, b);  // <= m
     if (mb == 0u) return;
@@ -1620,7 +1625,45 @@ __global__ __launch_bounds__(256) void k_numerics_sweep(unsigned long long *__re
     atomicAdd(out + 3, n_r);
 }
 
+// The one transcendental of the path (mod.rs:703: cos / sin of r1 = 2 pi rand01()) on EVERY argument it can see: rand01()
+// returns k * 2^-24, k < 2^24 (rand 0.8.5's f32 mapping), so r1 = (2 pi as f32) * (k * 2^-24) takes 2^24 values.  The device's
+// sincos_f32 against a table of the host instantiation of the same source (which tests/test_abi.py holds to the platform
+// libm on the same 2^24 arguments): out[0] = arguments whose sine or cosine differs in bits, out[1] = arguments compared.
+__global__ __launch_bounds__(256) void k_sincos_sweep(const uint32_t *__restrict__ want_sin, const uint32_t *__restrict__ want_cos,
+                                                      unsigned long long *__restrict__ out) {
+    unsigned long long bad = 0, n = 0;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < (1u << 24); k += gridDim.x * blockDim.x) {
+        const float r1 = (2.0f * 3.141592653589793f) * unit_f32(k << 8);  // shade_surface's expression
+        float s, c;
+        sincos_f32(r1, &s, &c);
+        bad += (__float_as_uint(s) != want_sin[k] || __float_as_uint(c) != want_cos[k]) ? 1u : 0u;
+        ++n;
+    }
+    if (bad) atomicAdd(out + 0, bad);
+    atomicAdd(out + 1, n);
+}
+
+// render_pixel's per-sample ray (mod.rs:805-843) for given (framebuffer index, sample) pairs, as the frame kernels make it:
+// form 0 = primary_ray (k_generate, k_mega, k_pass: column and row by division), form 1 = primary_ray_at with the column
+// and row precomputed (k_pass_cand keeps them per stream pixel in LDS).  For tests/kats_camera.py.
+__global__ __launch_bounds__(256) void k_primary_rays(FrameParams F, const uint32_t *__restrict__ pixel, const uint32_t *__restrict__ sample,
+                                                      uint32_t n, uint32_t form, float *__restrict__ o, float *__restrict__ d) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t pix = pixel[i], s = sample[i];
+    const PathRay r = form == 0u ? primary_ray<false>(F, pix, s) : primary_ray_at(F, pix, pix % F.width, F.height - 1u - pix / F.width, s);
+    o[3 * i + 0] = r.o.x, o[3 * i + 1] = r.o.y, o[3 * i + 2] = r.o.z;
+    d[3 * i + 0] = r.d.x, d[3 * i + 1] = r.d.y, d[3 * i + 2] = r.d.z;
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
+void launch_sincos_sweep(hipStream_t st, const uint32_t *want_sin, const uint32_t *want_cos, unsigned long long *out2) {
+    hipLaunchKernelGGL(k_sincos_sweep, dim3(2048), dim3(256), 0, st, want_sin, want_cos, out2);
+}
+void launch_primary_rays(hipStream_t st, const FrameParams &F, const uint32_t *pixel, const uint32_t *sample, uint32_t n, uint32_t form,
+                         float *o, float *d) {
+    hipLaunchKernelGGL(k_primary_rays, dim3((n + 255u) / 256u), dim3(256), 0, st, F, pixel, sample, n, form, o, d);
+}
 void launch_generate(hipStream_t st, uint32_t K, const FrameParams &F, const RayQueue &q, uint32_t *cnt0,
                      uint32_t cap, uint32_t s0, uint32_t s_here, uint32_t m) {
     if (F.probe)
@@ -1648,7 +1691,7 @@ void launch_intersect(hipStream_t st, uint32_t K, const DevScene &S, const RayQu
 void launch_shade(hipStream_t st, uint32_t K, const DevScene &S, const FrameParams &F, const RayQueue &qin,
                   const RayQueue &qout, const float2 *hit, const uint32_t *cnt_in, uint32_t *cnt_out, uint32_t cap,
                   unsigned long long *acc, uint32_t *flags, uint32_t m, uint32_t s0) {
-    const size_t lds = (size_t)3 * m * sizeof(unsigned long long) + 16;
+    const size_t lds = (size_t)pass_acc_slots(m) * sizeof(unsigned long long) + 16;
     ShadeParams P;
     P.idx_begin = F.idx_begin;
     P.npix = F.npix;

@@ -195,6 +195,8 @@ def product():
     L.pt_ctx_radiance.argtypes = [C.c_void_p, fp, fp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                   fp, C.POINTER(PtStats)]
     L.pt_ctx_numerics_sweep.argtypes = [C.c_void_p, u64p]
+    L.pt_ctx_sincos_sweep.argtypes = [C.c_void_p, u64p]
+    L.pt_ctx_primary_rays.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, u32p, u32p, C.c_uint32, C.c_uint32, fp, fp]
     L.pt_ctx_intersect_streams.argtypes = [C.c_void_p, fp, fp, C.c_uint32, C.c_uint32, fp, i32p]
     L.pt_ctx_intersect.argtypes = [C.c_void_p, fp, fp, C.c_uint32, fp, i32p, i32p, fp, fp]
     L.pt_ctx_intersect_bounds.argtypes = [C.c_void_p, C.c_uint32, fp, fp, C.c_uint32, i32p, fp, fp, fp]

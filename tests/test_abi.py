@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported():
 
 
 def test_version_and_struct_sizes():
-    assert L.pt_abi_version() == 4
+    assert L.pt_abi_version() == 5
     assert b"gfx950" in L.pt_version()
     # POD layout the Rust/cgo/ctypes side must match (include/ptrace.h)
     assert C.sizeof(ptlib.PtCamera) == 36

@@ -103,3 +103,13 @@ def test_bench_collective_at_world_size_1(gather):
     assert ("pt_comm_gather_frame" in b["config"]["collective"]) == (gather == "abi")
     assert a["config"]["ray_bounces_per_frame"] == b["config"]["ray_bounces_per_frame"] > 0
     assert b["config"]["image_hash"] == a["config"]["image_hash"]
+    # the diagnosis a multi-GPU run will need is in the line: per-rank render / gather times and bounces (min, max, mean over
+    # the ranks - here one), the gather's own time, and the identity of the kernels the profiles must have been measured on
+    assert a["per_rank"] is None and a["gather_ms"] is None and a["render_ms"] > 0
+    pr = b["per_rank"]
+    for k in ("render_ms", "gather_ms", "ray_bounces"):
+        assert pr[k]["min"] == pr[k]["max"] == pr[k]["mean"]
+    assert pr["ray_bounces"]["mean"] == b["config"]["ray_bounces_per_frame"] and pr["render_ms"]["mean"] > 0
+    assert b["gather_ms"] is not None and 0 <= b["gather_ms"] < 1e3 and abs(b["gather_ms"] - pr["gather_ms"]["mean"]) < 1e-6
+    assert len(b["config"]["kernel_isa_hash"]) == 16 and b["config"]["build_flags_complete"] is True
+    assert isinstance(b["roofline"]["profile_matches_binary"], bool) and "hbm_counter_frac" in b["roofline"] and b["roofline"]["l2_frac"] > 0

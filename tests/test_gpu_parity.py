@@ -102,6 +102,81 @@ def test_device_numerics_contract(gpu):
         assert list(out) == list(ph[4 * i:4 * i + 4])
 
 
+def test_device_sincos_on_every_reachable_argument(gpu):
+    """The diffuse bounce's cos / sin (mod.rs:703) on ALL 2^24 arguments r1 = 2 pi k 2^-24 it can see, on the device,
+    against the host instantiation of the same source - which is held to the oracle's restatement of glibc's algorithm here
+    (a sample) and, in tests/test_abi.py / test_oracle.py, to the platform libm on the same 2^24 arguments."""
+    L, ctx = gpu
+    out = (C.c_uint64 * 2)()
+    rc = L.pt_ctx_sincos_sweep(ctx, out)
+    assert rc == 0, L.pt_last_error()
+    assert out[1] == 1 << 24 and out[0] == 0, list(out)
+    O = ptlib.oracle()
+    rng = np.random.default_rng(5)
+    two_pi = np.float32(2.0) * np.float32(3.141592653589793)
+    s, c = C.c_float(), C.c_float()
+    for k in [0, 1, (1 << 24) - 1, 1 << 23, 1 << 22, 3 << 22] + [int(v) for v in rng.integers(0, 1 << 24, size=2000)]:
+        x = float(two_pi * (np.float32(k) * np.float32(2.0 ** -24)))
+        L.pt_host_sincos(x, C.byref(s), C.byref(c))
+        assert (s.value, c.value) == (O.pto_sinf(x), O.pto_cosf(x)), k
+
+
+def test_primary_rays_against_the_independent_restatement(gpu):
+    """render_pixel's sensor mapping on the DEVICE (pt_ctx_primary_rays: the functions the frame kernels call, both forms)
+    == tests/kats_camera.py's numpy-f32 reading of mod.rs:805-843 == the oracle's pto_primary_ray, bit for bit: corners,
+    centre, the four sub-pixels, r on both sides of 1.0 and exactly 1.0, non-square pixels, both `up` vectors."""
+    import kats_camera as K
+
+    L, ctx = gpu
+    O = ptlib.oracle()
+    groups = {}
+    for case in K.CASES:
+        cam, w, h, pix, smp, seed = case
+        groups.setdefault((id(cam), w, h, seed), []).append(case)
+    n_checked = 0
+    for cases in groups.values():
+        cam, w, h, _, _, seed = cases[0]
+        pc = ptlib.make_camera(cam["position"], cam["direction"], cam["focal_length"], cam["sensor_width"], cam["aspect_ratio"])
+        sc = ptlib.Scene("cam", pc, [ptlib.make_sphere((0, 0, -3), 1.0, (1, 1, 1), (0, 0, 0), "Diffuse")], [])
+        set_scene(gpu, sc)
+        pix = np.array([c[3] for c in cases], np.uint32)
+        smp = np.array([c[4] for c in cases], np.uint32)
+        n = len(cases)
+        for form in (0, 1):
+            o, d = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+            rc = L.pt_ctx_primary_rays(ctx, w, h, seed, pix.ctypes.data_as(ptlib.u32p), smp.ctypes.data_as(ptlib.u32p), n, form,
+                                       _np_f(o), _np_f(d))
+            assert rc == 0, L.pt_last_error()
+            for i, case in enumerate(cases):
+                want_o, want_d = K.expected(case)
+                assert np.array_equal(o[i].view(np.uint32), want_o.view(np.uint32)), (form, case, o[i], want_o)
+                assert np.array_equal(d[i].view(np.uint32), want_d.view(np.uint32)), (form, case, d[i], want_d)
+                n_checked += 1
+    assert n_checked == 2 * len(K.CASES)
+    # and in bulk against the oracle: every sample of a block of pixels of the bench frame, both forms
+    sc = ptlib.load_scene_py(ptlib.scene_path("cornell"))
+    set_scene(gpu, sc)
+    w, h, seed = 1024, 768, 1
+    rng = np.random.default_rng(3)
+    pix = rng.integers(0, w * h, size=4096, dtype=np.uint64).astype(np.uint32)
+    smp = rng.integers(0, 4096, size=4096, dtype=np.uint64).astype(np.uint32)
+    want_o, want_d = np.zeros((4096, 3), np.float32), np.zeros((4096, 3), np.float32)
+    oo, dd = (C.c_float * 3)(), (C.c_float * 3)()
+    for i in range(4096):
+        O.pto_primary_ray(C.byref(sc.cam), w, h, int(pix[i]), int(smp[i]), seed, oo, dd)
+        want_o[i], want_d[i] = list(oo), list(dd)
+    for form in (0, 1):
+        o, d = np.zeros((4096, 3), np.float32), np.zeros((4096, 3), np.float32)
+        rc = L.pt_ctx_primary_rays(ctx, w, h, seed, pix.ctypes.data_as(ptlib.u32p), smp.ctypes.data_as(ptlib.u32p), 4096, form,
+                                   _np_f(o), _np_f(d))
+        assert rc == 0, L.pt_last_error()
+        assert np.array_equal(o.view(np.uint32), want_o.view(np.uint32)) and np.array_equal(d.view(np.uint32), want_d.view(np.uint32))
+    # bad arguments are errors, not faults
+    assert L.pt_ctx_primary_rays(ctx, w, h, seed, pix.ctypes.data_as(ptlib.u32p), smp.ctypes.data_as(ptlib.u32p), 4096, 2, _np_f(o), _np_f(d)) == -1
+    bad = np.array([w * h], np.uint32)
+    assert L.pt_ctx_primary_rays(ctx, w, h, seed, bad.ctypes.data_as(ptlib.u32p), smp.ctypes.data_as(ptlib.u32p), 1, 0, _np_f(o), _np_f(d)) == -1
+
+
 @pytest.mark.parametrize("sid", ["cornell", "mesh", "three-spheres"])
 def test_intersect_ray_by_ray(gpu, sid):
     """Every ray the path tracer casts for a block of pixels: hit distance, object, triangle, hit point and
@@ -1541,6 +1616,18 @@ def test_memory_budget_changes_the_passes_not_the_image(gpu):
         assert L.pt_ctx_set_memory_budget(ctx, 0) == 0
     assert st1.passes == spp and st1.ray_bounces == st0.ray_bounces
     assert np.array_equal(small, whole)
+    # the budget also bounds an EXPLICIT rays_per_pass (round 3 applied it to the default size only): asked for the whole
+    # frame in one pass, got the passes the budget allows; without a budget the explicit size is taken as given
+    assert L.pt_ctx_set_memory_budget(ctx, 8 << 20) == 0
+    try:
+        small2, st2 = _render_dev(L, ctx, sc, w, h, spp, 4, rays_per_pass=w * h * spp)
+        sep, st3 = _render_dev(L, ctx, sc, w, h, spp, 4, flags=2, rays_per_pass=w * h * spp)  # level-by-level form: 352 B per primary
+    finally:
+        assert L.pt_ctx_set_memory_budget(ctx, 0) == 0
+    assert st2.passes == spp and st2.ray_bounces == st0.ray_bounces and np.array_equal(small2, whole)
+    assert st3.passes == -(-spp // ((8 << 20) // 352 // (w * h))) and np.array_equal(sep, whole)
+    free, st4 = _render_dev(L, ctx, sc, w, h, spp, 4, rays_per_pass=w * h * spp)
+    assert st4.passes == 1 and np.array_equal(free, whole)
 
 
 def test_default_pass_size_is_shared_by_pipelines_and_ranks(gpu):

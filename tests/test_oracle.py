@@ -429,3 +429,73 @@ def test_hand_derived_shading_kats(name, build, o, d, depth, want):
     mean = p_a * a.astype(np.float64) + (1.0 - p_a) * b.astype(np.float64)
     sd = np.abs(a.astype(np.float64) - b.astype(np.float64)) * np.sqrt(p_a * (1.0 - p_a) / n)
     assert np.all(np.abs(got - mean) <= 5.0 * sd + 1e-6), (name, got, mean, sd)
+
+
+# ------------------------------------------------------------------ render_pixel's sensor mapping (mod.rs:805-843)
+def _cam_of(d):
+    return ptlib.make_camera(d["position"], d["direction"], d["focal_length"], d["sensor_width"], d["aspect_ratio"])
+
+
+def test_kats_camera_philox_restatement_against_random123():
+    import kats_camera as K
+
+    for ctr, key, want in K.PHILOX7_KATS:
+        assert K.philox4x32(ctr, key) == want
+    # the numpy restatement's draws are the oracle's (pto_draw4: words through rand 0.8.5's map), tag 0
+    u = (C.c_float * 4)()
+    for _, _, _, pix, smp, seed in K.CASES:
+        L.pto_draw4(seed, pix, smp, 0, u)
+        u1, u2 = K.camera_draws(seed, pix, smp)
+        assert (u[0], u[1]) == (float(u1), float(u2))
+    # the cases reach both branches of the tent filter with both draws, and the branch point itself (r = 1.0 exactly)
+    draws = [K.camera_draws(seed, pix, smp) for _, _, _, pix, smp, seed in K.CASES]
+    for i in (0, 1):
+        assert any(d[i] < 0.5 for d in draws) and any(d[i] > 0.5 for d in draws) and any(d[i] == 0.5 for d in draws)
+    assert K.camera_draws(K.SEED_R1_IS_ONE, 0, 0)[0] == 0.5 and K.camera_draws(K.SEED_R2_IS_ONE, 0, 0)[1] == 0.5
+    assert K.tent(np.float32(1.0)) == 0.0 and K.tent(np.float32(2.0) * np.float32(0.5 - 2.0 ** -24)) < 0.0
+
+
+def test_primary_ray_against_the_independent_restatement():
+    """pto_primary_ray (what the oracle's render_pixel casts) == tests/kats_camera.py's numpy-f32 reading of
+    mod.rs:805-843 + mod.rs:211-232, bit for bit, on every case: corners, centre, the four sub-pixels, r on both sides of
+    1.0 and exactly 1.0, non-square pixels, both `up` vectors of orthogonals()."""
+    import kats_camera as K
+
+    o, d = (C.c_float * 3)(), (C.c_float * 3)()
+    for case in K.CASES:
+        cam, w, h, pix, smp, seed = case
+        want_o, want_d = K.expected(case)
+        pc = _cam_of(cam)
+        L.pto_primary_ray(C.byref(pc), w, h, pix, smp, seed, o, d)
+        got_o, got_d = np.array(list(o), np.float32), np.array(list(d), np.float32)
+        assert np.array_equal(got_o.view(np.uint32), want_o.view(np.uint32)), (case, got_o, want_o)
+        assert np.array_equal(got_d.view(np.uint32), want_d.view(np.uint32)), (case, got_d, want_d)
+    # by hand: the centre of the branch point.  r1 = r2 = 1.0 -> xfilter = yfilter = 0; pixel 0 of a 1x1 frame: x = y = 0,
+    # sample 3 -> xsub = ysub = 1: sx = sy = (0 + 0.5 * 1.5) / 1 - 0.5 = 0.25 exactly
+    cam = dict(position=(0.0, 0.0, 0.0), direction=(0.0, 0.0, -1.0), focal_length=0.5, sensor_width=2.0, aspect_ratio=2.0)
+    ro, rd = K.primary_ray(cam, 1, 1, 0, 3, np.float32(0.5), np.float32(0.5))
+    # su = normalize((0,0,-1) x (0,1,0)) * 2 = (1,0,0) * 2, sv = (su x dir) * 1 = (0,1,0); sensor = (0.5, 0.25, 0); lens = (0,0,-0.5)
+    assert list(ro) == [0.0, 0.0, -0.5]
+    want = np.array([-0.5, -0.25, -0.5], np.float32)
+    want = want * (np.float32(1.0) / np.sqrt(np.float32(0.5625)))
+    assert np.array_equal(rd, want) and list(rd) == [np.float32(-0.5) * np.float32(1.0 / 0.75), np.float32(-0.25) * np.float32(1.0 / 0.75),
+                                                      np.float32(-0.5) * np.float32(1.0 / 0.75)]
+
+
+# ------------------------------------------------------------------ whole frames in the reference's MOCK_RANDOM mode
+MOCK_FRAMES = [("cornell", 32, 4), ("mesh", 16, 2), ("three-spheres", 16, 4)]  # (scene, res_y, spp); width = res_y * 3 / 2
+
+
+@pytest.mark.parametrize("sid,res_y,spp", MOCK_FRAMES)
+def test_mock_random_frames_against_committed_ppm(sid, res_y, spp):
+    """tests/golden/mock_<scene>_<res_y>_<spp>.ppm = the file the reference writes for this frame with MOCK_RANDOM = true
+    (mod.rs:31-51, 1017-1018, 1031-1076) as the ORACLE renders it (tools/make_golden.py) - the fixed target of the cargo
+    diff INTEGRATION.md describes, and a drift guard on pto_render_mock / pto_format_ppm until someone can run it."""
+    sc = ptlib.load_scene_py(ptlib.scene_path(sid))
+    width = res_y * 3 // 2
+    img, cnt, draws = ptlib.oracle_render_mock(sc, width, res_y, spp)
+    n = L.pto_format_ppm(_np_f(img), width, res_y, spp, sid.encode(), 0, None, 0)
+    buf = C.create_string_buffer(n)
+    L.pto_format_ppm(_np_f(img), width, res_y, spp, sid.encode(), 0, buf, n)
+    want = open(os.path.join(ptlib.ROOT, "tests", "golden", "mock_%s_%d_%d.ppm" % (sid, res_y, spp)), "rb").read()
+    assert buf.raw[:n] == want

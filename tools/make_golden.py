@@ -66,9 +66,31 @@ def numerics_vectors():
     return dict(sincos_x=x, sin=s, cos=c, philox_ctr=ctr, philox_key=key, philox_out=out, gamma_x=g, gamma_int=gi)
 
 
+# (scene, res_y, spp): whole frames as the reference writes them with MOCK_RANDOM = true (mod.rs:31-51), width = res_y*3/2
+# as its GUI sets it (mod.rs:872-879) - rendered by the ORACLE (pto_render_mock + pto_format_ppm); the target a cargo holder
+# diffs against and a drift guard until then (tests/test_oracle.py holds the list too)
+MOCK_FRAMES = [("cornell", 32, 4), ("mesh", 16, 2), ("three-spheres", 16, 4)]
+
+
+def mock_ppm(sid, res_y, spp):
+    O = ptlib.oracle()
+    width = res_y * 3 // 2
+    sc = ptlib.load_scene_py(ptlib.scene_path(sid))
+    img, _, _ = ptlib.oracle_render_mock(sc, width, res_y, spp)
+    n = O.pto_format_ppm(_np_f(img), width, res_y, spp, sid.encode(), 0, None, 0)
+    buf = C.create_string_buffer(n)
+    O.pto_format_ppm(_np_f(img), width, res_y, spp, sid.encode(), 0, buf, n)
+    return buf.raw[:n]
+
+
 def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
+    for sid, res_y, spp in MOCK_FRAMES:
+        with open(os.path.join(out_dir, "mock_%s_%d_%d.ppm" % (sid, res_y, spp)), "wb") as f:
+            f.write(mock_ppm(sid, res_y, spp))
+    if len(sys.argv) > 1 and sys.argv[1] == "mock":  # only the MOCK_RANDOM frames (the .npz vectors stay as they are)
+        return
     for sid in SCENES:
         np.savez_compressed(os.path.join(out_dir, "scene_%s.npz" % sid), **scene_vectors(sid))
     np.savez_compressed(os.path.join(out_dir, "numerics.npz"), **numerics_vectors())

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turn the three PMC passes of tools/pmc_run.sh <tag> into profiles/<tag>_pmc_<what>.json and, per dominant kernel,
-profiles/r03_<kernel>_traffic.json (read by bench.py for roofline.traffic and for the VALU issue figure):
+profiles/<round>_<kernel>_traffic.json (read by bench.py for roofline.traffic and for the VALU issue figure):
   hbm_bytes_per_ray   (2 x FETCH_SIZE + WRITE_SIZE) / rays - the gfx950 correction of MI355X_MICROARCH.md's HBM section
   valu                dynamic VALU wave-instructions per ray x 64 (SQ_INSTS_VALU), VALU busy (SQ_ACTIVE_INST_VALU /
                       SQ_BUSY_CYCLES / 8), and the kernel's static issue-class mix (tools/isa_mix.py over
@@ -20,6 +20,10 @@ out = {k: summarise(os.path.join(ROOT, "gpurun_out", "pmc_%s_%s" % (tag, k))) fo
        if os.path.isdir(os.path.join(ROOT, "gpurun_out", "pmc_%s_%s" % (tag, k)))}
 line = [l for l in open(os.path.join(ROOT, "gpurun_out", "pmc_%s_sq.log" % tag)) if l.startswith("{")][-1]
 rays = json.loads(line)["config"]["ray_bounces_per_frame"]
+# the library the counters were collected on (bench.py prints its pt_kernel_isa_hash): bench.py prices a live rate with these
+# counts only when the library it has loaded carries the same hash
+isa_hash = json.loads(line)["config"].get("kernel_isa_hash")
+ROUND = tag[:3]  # "r04a" -> profiles/r04_<kernel>_traffic.json
 name = "%s_pmc_%s.json" % (tag, what)
 with open(os.path.join(ROOT, "profiles", name), "w") as f:
     json.dump({"command": "tools/pmc_run.sh %s %s" % (tag, bench_args), "rays_per_frame": rays, "passes": out}, f, indent=1)
@@ -77,6 +81,7 @@ for kname, sym, label in KERNELS:
             dynamic["wave_cycles_waiting_frac"] = m2["SQ_WAIT_ANY"] / m2["SQ_WAVE_CYCLES"]
     tr = {
         "kernel": clean,
+        "kernel_isa_hash": isa_hash,
         "rays": rays,
         "dispatches": sq["dispatches"],
         "FETCH_SIZE_bytes": fetch,
@@ -95,6 +100,6 @@ for kname, sym, label in KERNELS:
         },
     }
     done[clean] = tr
-    with open(os.path.join(ROOT, "profiles", "r03_%s_traffic.json" % clean), "w") as f:
+    with open(os.path.join(ROOT, "profiles", "%s_%s_traffic.json" % (ROUND, clean)), "w") as f:
         json.dump(tr, f, indent=1)
 print(json.dumps(done, indent=1))
