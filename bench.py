@@ -42,6 +42,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 L2_PEAK_GBS = 34500.0  # the eight XCDs' L2s together (MI355X_MICROARCH.md, "L2 (per XCD)": about 34.5 TB/s)
+LOADED_ISA_HASH = [None]  # pt_kernel_isa_hash() of the library in use (set in main)
 PROFILE_ROUNDS = ("r04", "r03", "r02")  # newest first: profiles/<round>_<kernel>_traffic.json
 VALU_CYCLES_PEAK = 256 * 4 * 2.4e9  # SIMD-cycles per second: 256 CUs x 4 SIMDs at the 2.4 GHz peak clock
 INTERSECT_BYTES_PER_RAY = 32  # k_intersect: 24 B (o, d) read + 8 B (t, id) written
@@ -127,7 +128,7 @@ def valu_figures(tr, kernel, rays_per_s, matches):
         return None
     if not matches:
         print("bench.py: warning: %s was measured on another build of the kernels (profile %s, library %s): no valu_roofline"
-              % (tr["_path"], tr.get("kernel_isa_hash"), "loaded"), file=sys.stderr)
+              % (tr["_path"], tr.get("kernel_isa_hash"), LOADED_ISA_HASH[0]), file=sys.stderr)
         return None
     try:
         dyn = valu.get("dynamic_mix")
@@ -246,6 +247,7 @@ def main():
     import torch
 
     pkg = importlib.import_module("path-tracer-rust_amd")
+    LOADED_ISA_HASH[0] = pkg.kernel_isa_hash()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

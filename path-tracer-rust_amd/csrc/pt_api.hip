@@ -130,6 +130,7 @@ struct pt_ctx {
     DevBuf<MatRec> d_mats;
     DevBuf<TriShade> d_tshade;
     DevBuf<BvhNode> d_nodes;
+    DevBuf<BvhNode4> d_nodes4;
     DevBuf<SphPairRec> d_sph;
     DevBuf<FlatPairRec> d_flat;
     DevBuf<CandPairRec> d_cand;
@@ -713,6 +714,7 @@ void pt_ctx_destroy(pt_ctx *c) {
     c->d_mats.release();
     c->d_tshade.release();
     c->d_nodes.release();
+    c->d_nodes4.release();
     c->d_sph.release();
     c->d_flat.release();
     c->d_cand.release();
@@ -755,7 +757,8 @@ int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uin
     int rc;
     if ((rc = c->d_objs.ensure(fs.objs.size())) || (rc = c->d_opairs.ensure(fs.obj_pairs.size())) || (rc = c->d_tris.ensure(fs.tri_pairs.size())) ||
         (rc = c->d_mats.ensure(fs.mats.size())) || (rc = c->d_tshade.ensure(fs.tri_shade.size())) ||
-        (rc = c->d_nodes.ensure(fs.bvh_nodes.size())) || (rc = c->d_sph.ensure(fs.sph_pairs.size())) ||
+        (rc = c->d_nodes.ensure(fs.bvh_nodes.size())) || (rc = c->d_nodes4.ensure(fs.bvh_nodes4.size())) ||
+        (rc = c->d_sph.ensure(fs.sph_pairs.size())) ||
         (rc = c->d_flat.ensure(fs.flat_pairs.size())) || (rc = c->d_cand.ensure(fs.cand_pairs.size())) ||
         (rc = c->d_rank_id.ensure(fs.rank_id.size())) || (rc = c->d_surf.ensure(fs.surf.size())) ||
         (rc = c->d_tri_rank.ensure(fs.tri_rank.size())) || (rc = c->d_bvh_meshes.ensure(fs.bvh_meshes.size())))
@@ -777,6 +780,10 @@ int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uin
     if (!fs.bvh_nodes.empty())
         HIP_TRY(hipMemcpy(c->d_nodes.p, fs.bvh_nodes.data(), fs.bvh_nodes.size() * sizeof(BvhNode),
                           hipMemcpyHostToDevice));
+    if (!fs.bvh_nodes4.empty())
+        HIP_TRY(hipMemcpy(c->d_nodes4.p, fs.bvh_nodes4.data(), fs.bvh_nodes4.size() * sizeof(BvhNode4), hipMemcpyHostToDevice));
+    c->scene.bvh_nodes4 = c->d_nodes4.p;
+    c->scene.n_bvh_nodes4 = (uint32_t)fs.bvh_nodes4.size();
     if (!fs.sph_pairs.empty())
         HIP_TRY(hipMemcpy(c->d_sph.p, fs.sph_pairs.data(), fs.sph_pairs.size() * sizeof(SphPairRec), hipMemcpyHostToDevice));
     if (!fs.flat_pairs.empty())

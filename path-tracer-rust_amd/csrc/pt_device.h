@@ -84,6 +84,20 @@ struct alignas(16) BvhNode {
     int32_t c[2];
     uint32_t pad[2];
 };
+// The same tree FOUR children wide, for the walk queue of k_pass_cand / k_mega (bvh_closest_queue): the binary tree with
+// two levels folded into one wherever a child is an inner node (the child with the larger box first), so a walk visits
+// half the nodes - what a (ray, node) item costs is mostly its trip through the queue (pop, the owner's ray constants,
+// pushes), not its box arithmetic.  The boxes are the binary tree's (padded the same way), a child reference is a
+// node4 index (>= 0) or the binary tree's leaf reference (< 0).  A node with fewer than four children fills up with boxes
+// of NaN: min / max ignore a NaN, so such a box has tin = 0, tout = NaN, and `tin <= tout * (1 + e)` is false - never hit;
+// their reference repeats child 0's (harmless if it ever were).  Component-interleaved in pairs (0,1) and (2,3) like BvhNode.
+struct alignas(16) BvhNode4 {
+    float lox[4], loy[4], loz[4];
+    float hix[4], hiy[4], hiz[4];
+    int32_t c[4];
+    uint32_t pad[4];
+};
+static_assert(sizeof(BvhNode4) == 128, "BvhNode4 layout");
 constexpr int32_t kNoBvh = 0x7fffffff;
 constexpr uint32_t kNoTri = 0x7fffffffu;
 constexpr uint32_t kBvhStack = 24;          // per-lane traversal stack entries (LDS; u16 each when nodes are staged)
@@ -93,8 +107,10 @@ constexpr uint32_t kBvhMinTris = 16;        // meshes with fewer triangles are s
 // spent as tests (k_pass_bvh, depth-first walks: 1 record per leaf 14.4, 2: 15.4, 4: 15.5, 8: 15.2 G bounces/s on
 // mesh.json).  With the box tests dense too (k_pass_cand's walk queue) the balance moves back a little:
 // 1: 19.5, 2: 20.0, 3: 20.2, 4: 19.8; and without levels (round 3) 2: 26.5, 3: 26.8, 4: 26.2 (640 000 triangles: 25.9 / 25.6 / 25.3).
+// With the four-wide tree (round 4: half the node visits) smaller leaves pay: 1: 27.7, 2: 28.4, 3: 26.0, 4: 25.7 (binary tree,
+// same build: 2: 26.3, 3: 26.5).
 #ifndef PT_BVH_LEAF_PAIRS
-#define PT_BVH_LEAF_PAIRS 3
+#define PT_BVH_LEAF_PAIRS 2
 #endif
 constexpr uint32_t kBvhLeafPairs = PT_BVH_LEAF_PAIRS;
 constexpr uint32_t kBvhLeafBits = kBvhLeafPairs <= 2 ? 1 : (kBvhLeafPairs <= 4 ? 2 : (kBvhLeafPairs <= 8 ? 3 : 4));
@@ -178,7 +194,8 @@ struct alignas(16) TriShade {
 struct alignas(16) BvhMeshRec {
     float cx, cy, cz, rr;  // bounding sphere in world space, radius squared
     int32_t root;          // node index (>= 0) or a leaf reference (< 0: the whole mesh is one leaf)
-    uint32_t pad[3];
+    int32_t root4;         // the same in the four-wide tree (DevScene.bvh_nodes4)
+    uint32_t pad[2];
 };
 static_assert(sizeof(BvhMeshRec) == 32, "BvhMeshRec layout");
 
@@ -189,6 +206,8 @@ struct DevScene {
     const MatRec *mats;
     const TriShade *tri_shade;
     const BvhNode *bvh_nodes;
+    const BvhNode4 *bvh_nodes4;  // the four-wide form of the same trees (walk queue)
+    uint32_t n_bvh_nodes4;
     uint32_t n_objs;
     uint32_t n_tris;
     uint32_t n_bvh_nodes;  // 0: no mesh of the scene has a BVH (or BVH use is switched off for this frame)
@@ -1051,6 +1070,201 @@ __device__ __forceinline__ void bvh_closest_queue(const DevScene &S, NodePtr nod
     }
 }
 
+// Slab test of the four child boxes of a BvhNode4 (two packed pairs), verdicts as wave masks (see hit_boxes_masks)
+__device__ __forceinline__ void hit_boxes4_masks(const BvhNode4 &n, f32x2 ivx, f32x2 ivy, f32x2 ivz, f32x2 oix, f32x2 oiy, f32x2 oiz,
+                                                 float bound, uint64_t m[4], float tin_out[4]) {
+    const f32x2 zero = splat2(0.0f);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const f32x2 lx = {n.lox[2 * p], n.lox[2 * p + 1]}, ly = {n.loy[2 * p], n.loy[2 * p + 1]}, lz = {n.loz[2 * p], n.loz[2 * p + 1]};
+        const f32x2 hx = {n.hix[2 * p], n.hix[2 * p + 1]}, hy = {n.hiy[2 * p], n.hiy[2 * p + 1]}, hz = {n.hiz[2 * p], n.hiz[2 * p + 1]};
+        const f32x2 ax = __builtin_elementwise_fma(lx, ivx, -oix), bx = __builtin_elementwise_fma(hx, ivx, -oix);
+        const f32x2 ay = __builtin_elementwise_fma(ly, ivy, -oiy), by = __builtin_elementwise_fma(hy, ivy, -oiy);
+        const f32x2 az = __builtin_elementwise_fma(lz, ivz, -oiz), bz = __builtin_elementwise_fma(hz, ivz, -oiz);
+        const f32x2 tin = __builtin_elementwise_max(
+            __builtin_elementwise_max(__builtin_elementwise_min(ax, bx), __builtin_elementwise_min(ay, by)),
+            __builtin_elementwise_max(__builtin_elementwise_min(az, bz), zero));
+        const f32x2 tout = __builtin_elementwise_min(
+            __builtin_elementwise_min(__builtin_elementwise_max(ax, bx), __builtin_elementwise_max(ay, by)),
+            __builtin_elementwise_max(az, bz));
+        const f32x2 lim = tout * splat2(1.0000005f);
+        m[2 * p] = __builtin_amdgcn_ballot_w64(tin[0] <= lim[0]) & __builtin_amdgcn_ballot_w64(tin[0] <= bound);
+        m[2 * p + 1] = __builtin_amdgcn_ballot_w64(tin[1] <= lim[1]) & __builtin_amdgcn_ballot_w64(tin[1] <= bound);
+        tin_out[2 * p] = tin[0];
+        tin_out[2 * p + 1] = tin[1];
+    }
+}
+
+// bvh_closest_queue over the FOUR-WIDE tree (round 4; DevScene.bvh_nodes4, BvhMeshRec.root4): the same queue of (ray, node)
+// items and the same leaf list, but an item tests four boxes and pushes up to four children, so a walk sends half as many
+// items through the queue - and what an item costs is mostly that trip (pop, the owner's ray constants by ds_bpermute, the
+// pushes), not its box arithmetic.  No near-before-far order among the pushes: measured on mesh.json (walk statistics, and
+// an offline replay of the frame's rays), ordering buys nothing - the boxes of a thin surface mesh overlap, 99 % of the
+// popped items are still inside their owner's bound - and its compare / select instructions are not free.  `nodes4` is
+// LDS (staged) or global memory; `nodes2` (the binary tree, global memory) serves the depth-first second walk of rays whose
+// pushes did not fit.
+template <class NodePtr4>
+__device__ __forceinline__ void bvh_closest_queue4(const DevScene &S, NodePtr4 nodes4, const WalkQueue &Q, unsigned long long *keys,
+                                                   bool walk, vec3 o, vec3 d, int32_t root4, int32_t root2, float best_t, float &mt,
+                                                   int32_t &mid) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t act = __builtin_amdgcn_ballot_w64(true);
+    const uint32_t n_act = (uint32_t)__builtin_popcountll(act);
+    const uint32_t my = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+    auto prefix = [](uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
+    auto count = [](uint64_t m) { return (uint32_t)__builtin_popcountll(m); };
+    if (walk) keys[lane] = ((unsigned long long)(__float_as_uint(best_t) - 1u) << 32) | 0xffffffffull;
+    if (my == 0u) Q.redo[0] = Q.redo[1] = 0u;
+    const float big = 1e18f;  // see bvh_closest
+    const vec3 inv = mk(__builtin_fmaxf(__builtin_fminf(1.0f / d.x, big), -big),
+                        __builtin_fmaxf(__builtin_fminf(1.0f / d.y, big), -big),
+                        __builtin_fmaxf(__builtin_fminf(1.0f / d.z, big), -big));
+    const vec3 oi = mk(o.x * inv.x, o.y * inv.y, o.z * inv.z);
+    uint32_t q_count, n_leaf;  // wave-uniform: box tests in ent[0, q_count), leaves in ent[cap - n_leaf, cap)
+    {
+        const uint64_t m_node = __builtin_amdgcn_ballot_w64(walk && root4 >= 0), m_leaf = __builtin_amdgcn_ballot_w64(walk && root4 < 0);
+        q_count = count(m_node);
+        n_leaf = count(m_leaf);
+        if (walk && root4 >= 0) Q.ent[prefix(m_node)] = make_uint2(lane | ((uint32_t)root4 << 6), 0u);
+        if (walk && root4 < 0) Q.ent[Q.cap - 1u - prefix(m_leaf)] = make_uint2(lane | ((uint32_t)~root4 << 6), 0u);
+    }
+    PT_WSTAT(S, 0, q_count + n_leaf);  // walks
+    PT_WSTAT(S, 10, 1);                // wave-walks
+    for (;;) {
+        if (q_count == 0u && n_leaf == 0u) break;
+        if (q_count != 0u) {
+            PT_PHASE(kPhWalkBox);
+            const uint32_t c = q_count < n_act ? q_count : n_act;
+            q_count -= c;
+            const bool has = my < c;
+            uint2 e = make_uint2(lane, 0u);
+            if (has) e = Q.ent[q_count + my];
+            const uint32_t owner = e.x & 63u;
+            const int sel = (int)(owner << 2);
+            const float r_ivx = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(inv.x)));
+            const float r_ivy = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(inv.y)));
+            const float r_ivz = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(inv.z)));
+            const float r_oix = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(oi.x)));
+            const float r_oiy = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(oi.y)));
+            const float r_oiz = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(oi.z)));
+            const float bound = __uint_as_float((uint32_t)(load_key(&keys[owner]) >> 32) + 1u);
+            const uint64_t m_valid = __builtin_amdgcn_ballot_w64(has) & ~__builtin_amdgcn_ballot_w64(__uint_as_float(e.y) > bound);
+            PT_WSTAT(S, 1, 1);                                   // batches of box tests
+            PT_WSTAT(S, 2, c);                                   // items
+            PT_WSTAT(S, 3, __builtin_popcountll(m_valid));       // ... still worth testing
+            uint64_t m_h[4];
+            float tin[4];
+            const BvhNode4 n = nodes4[e.x >> 6];  // (lanes without an item: node 0 with their own ray, a harmless read)
+            hit_boxes4_masks(n, splat2(r_ivx), splat2(r_ivy), splat2(r_ivz), splat2(r_oix), splat2(r_oiy), splat2(r_oiz), bound, m_h, tin);
+            uint64_t m_n[4], m_l[4];
+            uint32_t add_q = 0u, add_l = 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint64_t neg = __builtin_amdgcn_ballot_w64(n.c[j] < 0);
+                m_h[j] &= m_valid;
+                m_n[j] = m_h[j] & ~neg;
+                m_l[j] = m_h[j] & neg;
+                add_q += count(m_n[j]);
+                add_l += count(m_l[j]);
+            }
+            if (q_count + n_leaf + add_q + add_l > Q.cap) {  // wave-uniform: no room - these rays are walked again afterwards
+                if (__builtin_amdgcn_inverse_ballot_w64(m_h[0] | m_h[1] | m_h[2] | m_h[3])) atomicOr(&Q.redo[owner >> 5], 1u << (owner & 31u));
+                PT_WSTAT(S, 11, 1);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (__builtin_amdgcn_inverse_ballot_w64(m_n[j]))
+                        Q.ent[q_count + prefix(m_n[j])] = make_uint2(owner | ((uint32_t)n.c[j] << 6), __float_as_uint(tin[j]));
+                    q_count += count(m_n[j]);
+                    if (__builtin_amdgcn_inverse_ballot_w64(m_l[j]))
+                        Q.ent[Q.cap - 1u - (n_leaf + prefix(m_l[j]))] = make_uint2(owner | ((uint32_t)~n.c[j] << 6), __float_as_uint(tin[j]));
+                    n_leaf += count(m_l[j]);
+                }
+            }
+        }
+        while (n_leaf >= n_act || (q_count == 0u && n_leaf != 0u)) {
+            PT_PHASE(kPhWalkLeaf);
+            const uint32_t cnt = n_leaf < n_act ? n_leaf : n_act;
+            bool valid = my < cnt;
+            uint2 e = make_uint2(lane, 0u);
+            if (valid) e = Q.ent[Q.cap - n_leaf + my];
+            n_leaf -= cnt;
+            const uint32_t owner = e.x & 63u;
+            const int sel = (int)(owner << 2);
+            vec3 ro, rd;
+            ro.x = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(o.x)));
+            ro.y = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(o.y)));
+            ro.z = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(o.z)));
+            rd.x = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(d.x)));
+            rd.y = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(d.y)));
+            rd.z = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(d.z)));
+            const float bound = __uint_as_float((uint32_t)(load_key(&keys[owner]) >> 32) + 1u);
+            valid = valid && !(__uint_as_float(e.y) > bound);
+            PT_WSTAT(S, 5, 1);
+            PT_WSTAT(S, 6, cnt);
+            PT_WSTAT(S, 12, __builtin_popcountll(__builtin_amdgcn_ballot_w64(valid)));  // leaves still worth testing
+            const uint32_t code = e.x >> 6;
+            const uint32_t first = leaf_first(code), lc = valid ? leaf_count(code) : 0u;
+            for (uint32_t r = 0; r < kBvhLeafPairs; ++r) {
+                const bool has = r < lc;
+                if (__builtin_amdgcn_ballot_w64(has) == 0ull) break;
+                if (has) {
+                    const TriPairRec tr = S.tri_pairs[first + r];
+                    unsigned long long k2[2];
+                    float th[2];
+                    pair_test_keys(tr, ro, rd, k2, th);
+                    atomicMin(&keys[owner], k2[0]);
+                    atomicMin(&keys[owner], k2[1]);
+                }
+            }
+        }
+    }
+    PT_PHASE(kPhWalkGate);
+    if (walk) {
+        const unsigned long long key = load_key(&keys[lane]);
+        if ((uint32_t)key != 0xffffffffu) {
+            mt = __uint_as_float((uint32_t)(key >> 32) + 1u);
+            mid = (int32_t)(uint32_t)key;
+        }
+    }
+    // rays whose pushes were dropped: depth-first from the root of the binary tree, with the bound found so far
+    const uint32_t redo = __atomic_load_n(&Q.redo[lane >> 5], __ATOMIC_RELAXED);
+    const bool again = walk && ((redo >> (lane & 31u)) & 1u) != 0u;
+    if (__builtin_amdgcn_ballot_w64(again) != 0ull) {
+        if (again) {
+            StackDyn codec;
+            codec.narrow = (S.bvh_in_lds & 2u) != 0u;
+            codec.c16.pair_base = S.bvh_pair_base;
+            const uint32_t eb = codec.entry_bytes();
+            LeafLds L;  // [stacks: bvh_stack x 64 x u16|u32][leaf list: kLeafListCap x u32] in the queue's area
+            L.keys = keys;
+            L.list = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(Q.ent) + S.bvh_stack * 64u * eb);
+            float mt2 = __builtin_inff();
+            int32_t mid2 = -1;
+            bvh_closest_postponed(S, S.bvh_nodes, codec, reinterpret_cast<char *>(Q.ent) + lane * eb, 64u * eb, L, o, d, root2,
+                                  __builtin_fminf(best_t, mt), mt2, mid2);
+            if (mid2 >= 0 && (mid < 0 || mt2 < mt || (mt2 == mt && (uint32_t)mid2 < (uint32_t)mid))) {
+                mt = mt2;
+                mid = mid2;
+            }
+        }
+    }
+}
+
+// Which walker k_pass_cand / k_mega's candidate forms use (A/B builds; the tests hold both to the same bits):
+//   2 (default)  bvh_closest_queue4: the walk queue over the four-wide tree
+//   0            bvh_closest_queue: the walk queue over the binary tree (rounds 2-3)
+// (Round 4 also built a third form - lanes that keep an item while they DESCEND, going on with the nearer of two children
+// that are hit and pushing only the farther one onto a pool that idle lanes refill from, sixteen at a time: the order of a
+// depth-first walk per ray at the density of the queue.  Bit-identical, and no faster: 25.8 against 26.4 G bounces/s on
+// mesh.json - 14.3 node visits and 5.2 leaves per walk as before, 89 % of the far subtrees still inside their owner's
+// bound when popped: on a thin surface mesh the boxes along a ray overlap, there is little for best-t pruning to prune,
+// and an offline replay of the frame's rays against the same tree says so too: 10.2 / 2.7 with ideal depth-first order
+// against 12.9 / 3.9 with none.)
+#ifndef PT_WALK_FORM
+#define PT_WALK_FORM 2
+#endif
+
 // LDS carve-up of the kernels that intersect: [BvhNode x n_bvh_nodes][u16 stack: kBvhStack x blockDim] when the
 // nodes are staged, else [u32 stack: kBvhStack x blockDim] alone (nodes read from global memory)
 __device__ __forceinline__ void stage_bvh(const DevScene &S, uint4 *lds) {
@@ -1307,13 +1521,12 @@ struct CandRing {
 // if (plane - origin) * sign(d_a) > 0: about two thirds of the self-candidates go (the origin is on the inner side of the plane,
 // or exactly on it).
 template <int AXIS, bool EXACT>
-__device__ __forceinline__ void filter_flat(const FlatPairRec &f, vec3 o, vec3 d, vec3 inv, vec3 sgn, float bound, uint64_t valid_m,
+__device__ __forceinline__ void filter_flat(const FlatPairRec &f, vec3 o, vec3 d, vec3 inv, float bound, uint64_t valid_m,
                                             uint64_t graze, uint64_t *m0, uint64_t *m1) {
     const float oa = AXIS == 0 ? o.x : (AXIS == 1 ? o.y : o.z), ob = AXIS == 0 ? o.y : (AXIS == 1 ? o.z : o.x),
                 oc = AXIS == 0 ? o.z : (AXIS == 1 ? o.x : o.y);
     const float db = AXIS == 0 ? d.y : (AXIS == 1 ? d.z : d.x), dc = AXIS == 0 ? d.z : (AXIS == 1 ? d.x : d.y);
     const float ia = AXIS == 0 ? inv.x : (AXIS == 1 ? inv.y : inv.z);
-    const float sa = AXIS == 0 ? sgn.x : (AXIS == 1 ? sgn.y : sgn.z);  // +-1 with the sign of d_a
     const f32x2 tv = ld2(f.pc) - splat2(oa);  // -(tvec_a) of mod.rs:577: exact sign, zero iff the origin is on the plane
     const f32x2 t2 = tv * splat2(ia);         // distance to the plane (approximate reciprocal)
     const f32x2 yb = __builtin_elementwise_fma(splat2(db), t2, splat2(ob)) - ld2(f.cb);
@@ -1321,13 +1534,15 @@ __device__ __forceinline__ void filter_flat(const FlatPairRec &f, vec3 o, vec3 d
     const f32x2 lim = splat2(bound) + ld2(f.tpad);
     uint64_t in[2];
     if (EXACT) {  // (records with FlatPairRec.sign_exact: a loop of their own, cand_filter_and_drain)
-        const f32x2 ts = tv * splat2(sa);  // > 0: the ray moves towards the plane (exact: a product with +-1)
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
             in[hf] = __builtin_amdgcn_ballot_w64(f_abs(yb[hf]) <= f.hb[hf]) & __builtin_amdgcn_ballot_w64(f_abs(zc[hf]) <= f.hc[hf]) &
                      __builtin_amdgcn_ballot_w64(t2[hf] <= lim[hf]);
         // the sign test also holds for grazing rays (it does not use the reciprocal): it is applied to them too
-        const uint64_t fwd0 = __builtin_amdgcn_ballot_w64(ts[0] > 0.0f), fwd1 = __builtin_amdgcn_ballot_w64(ts[1] > 0.0f);
+        // "the ray moves towards the plane", (plane - origin) * sign(d_a) > 0, read off the approximate distance: v_rcp_f32 keeps
+        // the sign of d_a (+-0 -> +-inf) and its magnitude is at least 1 - 2^-23 (a unit direction), so tv * ia has the sign of
+        // tv * sign(d_a), is never rounded to zero for tv != 0, and is NaN (0 * inf) or +-0 - not > 0 - for tv = 0
+        const uint64_t fwd0 = __builtin_amdgcn_ballot_w64(t2[0] > 0.0f), fwd1 = __builtin_amdgcn_ballot_w64(t2[1] > 0.0f);
         *m0 = f.pair[0] != kNoPair ? ((graze | in[0]) & fwd0 & valid_m) : 0ull;
         *m1 = f.pair[1] != kNoPair ? ((graze | in[1]) & fwd1 & valid_m) : 0ull;
         return;
@@ -1368,6 +1583,11 @@ __device__ __forceinline__ unsigned long long cand_spheres(const DevScene &S, ve
     *best_out = best_t;
     return ((unsigned long long)__float_as_uint(best_t) << 32) | best_rank;
 }
+// (Round 4 tried to run the tail - square root, two roots, the 1e-4 tests - once per trip instead of once per sphere: a lane
+// NOTES the sphere whose discriminant is non-negative (b, det, rank) and the tail runs after the last record, and in between
+// only when a lane that already holds one meets a second.  Same keys, and no fewer instructions: 847 against 848 per bounce
+// (PMC) - some lane of 64 unrelated rays points at two of cornell's four spheres in nearly every trip, also when spheres
+// behind the origin are left out (852: the two extra compares per sphere).)
 
 // One dense batch: the `count` (<= 64) oldest ring entries.  Every lane of the wave takes part.  An entry's ray is read
 // from its slot in LDS (k_pass_cand keeps the rays of the two chunks in flight there).
@@ -1458,16 +1678,15 @@ __device__ __forceinline__ void cand_filter_and_drain(const DevScene &S, const C
     // rays that graze the planes of an axis (|d_a| < kGrazing, or NaN): not judged by the filters of that axis
     const uint64_t gz_x = __builtin_amdgcn_ballot_w64(!(f_abs(d.x) >= kGrazing)), gz_y = __builtin_amdgcn_ballot_w64(!(f_abs(d.y) >= kGrazing)),
                    gz_z = __builtin_amdgcn_ballot_w64(!(f_abs(d.z) >= kGrazing));
-    const vec3 sgn = mk(__builtin_copysignf(1.0f, d.x), __builtin_copysignf(1.0f, d.y), __builtin_copysignf(1.0f, d.z));
     for (uint32_t p = 0; p < S.n_flat_exact; ++p) {  // the records with the exact sign rule (the host puts them first)
         const FlatPairRec f = ld_uniform(S.flat_pairs + p);
         uint64_t m0, m1;
         if (f.axis == 0u)
-            filter_flat<0, true>(f, o, d, inv, sgn, bound, valid_m, gz_x, &m0, &m1);
+            filter_flat<0, true>(f, o, d, inv, bound, valid_m, gz_x, &m0, &m1);
         else if (f.axis == 1u)
-            filter_flat<1, true>(f, o, d, inv, sgn, bound, valid_m, gz_y, &m0, &m1);
+            filter_flat<1, true>(f, o, d, inv, bound, valid_m, gz_y, &m0, &m1);
         else
-            filter_flat<2, true>(f, o, d, inv, sgn, bound, valid_m, gz_z, &m0, &m1);
+            filter_flat<2, true>(f, o, d, inv, bound, valid_m, gz_z, &m0, &m1);
         push2(m0, f.pair[0], m1, f.pair[1]);
         drain();
     }
@@ -1475,11 +1694,11 @@ __device__ __forceinline__ void cand_filter_and_drain(const DevScene &S, const C
         const FlatPairRec f = ld_uniform(S.flat_pairs + p);
         uint64_t m0, m1;
         if (f.axis == 0u)
-            filter_flat<0, false>(f, o, d, inv, sgn, bound, valid_m, gz_x, &m0, &m1);
+            filter_flat<0, false>(f, o, d, inv, bound, valid_m, gz_x, &m0, &m1);
         else if (f.axis == 1u)
-            filter_flat<1, false>(f, o, d, inv, sgn, bound, valid_m, gz_y, &m0, &m1);
+            filter_flat<1, false>(f, o, d, inv, bound, valid_m, gz_y, &m0, &m1);
         else
-            filter_flat<2, false>(f, o, d, inv, sgn, bound, valid_m, gz_z, &m0, &m1);
+            filter_flat<2, false>(f, o, d, inv, bound, valid_m, gz_z, &m0, &m1);
         push2(m0, f.pair[0], m1, f.pair[1]);
         drain();
     }
@@ -1590,7 +1809,11 @@ __device__ __forceinline__ unsigned long long walk_deferred_keys(const DevScene 
         if (__builtin_amdgcn_ballot_w64(pass) == 0ull) continue;
         float mt = __builtin_inff();
         int32_t mid = -1;
+#if PT_WALK_FORM == 2
+        bvh_closest_queue4(S, nodes, Q, wave_keys, pass, o, d, bm.root4, bm.root, __uint_as_float((uint32_t)(key >> 32)), mt, mid);
+#else
         bvh_closest_queue(S, nodes, Q, wave_keys, pass, o, d, bm.root, __uint_as_float((uint32_t)(key >> 32)), mt, mid);
+#endif
         bool won = false;
         if (pass && mid >= 0) {
             const unsigned long long k2 = ((unsigned long long)__float_as_uint(mt) << 32) | S.tri_rank[mid];
@@ -1602,6 +1825,17 @@ __device__ __forceinline__ unsigned long long walk_deferred_keys(const DevScene 
     }
     return key;
 }
+
+// the nodes the walker of the candidate forms reads (walk_deferred_keys' `nodes`: global memory, or the workgroup's LDS copy)
+#if PT_WALK_FORM == 2
+typedef BvhNode4 WalkNode;
+__device__ __forceinline__ const WalkNode *walk_nodes(const DevScene &S) { return S.bvh_nodes4; }
+__host__ __device__ inline uint32_t walk_node_count(const DevScene &S) { return S.n_bvh_nodes4; }
+#else
+typedef BvhNode WalkNode;
+__device__ __forceinline__ const WalkNode *walk_nodes(const DevScene &S) { return S.bvh_nodes; }
+__host__ __device__ inline uint32_t walk_node_count(const DevScene &S) { return S.n_bvh_nodes; }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 struct PathRay {

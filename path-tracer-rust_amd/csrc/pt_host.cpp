@@ -212,6 +212,51 @@ struct BvhBuilder {
     }
 };
 
+// The binary tree below `ref` four children wide (BvhNode4): a node's children are its two children, and while there is
+// room the inner child with the largest box is replaced by ITS two children - boxes and leaf references are the binary
+// tree's.  Returns the reference in the wide tree (a leaf reference stays what it is).
+int32_t widen(const std::vector<BvhNode> &bin, int32_t ref, std::vector<BvhNode4> &wide) {
+    if (ref < 0) return ref;
+    struct Kid {
+        int32_t ref;
+        float lo[3], hi[3];
+    };
+    auto kid_of = [&](const BvhNode &n, int h) {
+        Kid k;
+        k.ref = n.c[h];
+        k.lo[0] = n.lox[h], k.lo[1] = n.loy[h], k.lo[2] = n.loz[h];
+        k.hi[0] = n.hix[h], k.hi[1] = n.hiy[h], k.hi[2] = n.hiz[h];
+        return k;
+    };
+    auto area = [](const Kid &k) {
+        const float dx = k.hi[0] - k.lo[0], dy = k.hi[1] - k.lo[1], dz = k.hi[2] - k.lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    std::vector<Kid> kids = {kid_of(bin[(size_t)ref], 0), kid_of(bin[(size_t)ref], 1)};
+    while (kids.size() < 4u) {
+        int best = -1;
+        for (int i = 0; i < (int)kids.size(); ++i)
+            if (kids[(size_t)i].ref >= 0 && (best < 0 || area(kids[(size_t)i]) > area(kids[(size_t)best]))) best = i;
+        if (best < 0) break;
+        const BvhNode &n = bin[(size_t)kids[(size_t)best].ref];
+        kids[(size_t)best] = kid_of(n, 0);  // (the first child takes the parent's place: the order stays a function of the scene)
+        kids.insert(kids.begin() + best + 1, kid_of(n, 1));
+    }
+    const size_t at = wide.size();
+    wide.push_back(BvhNode4{});
+    const float nan = std::numeric_limits<float>::quiet_NaN();
+    int32_t refs[4];
+    for (size_t j = 0; j < 4u; ++j) refs[j] = j < kids.size() ? widen(bin, kids[j].ref, wide) : 0;
+    BvhNode4 &w = wide[at];
+    for (size_t j = 0; j < 4u; ++j) {
+        const bool has = j < kids.size();
+        w.lox[j] = has ? kids[j].lo[0] : nan, w.loy[j] = has ? kids[j].lo[1] : nan, w.loz[j] = has ? kids[j].lo[2] : nan;
+        w.hix[j] = has ? kids[j].hi[0] : nan, w.hiy[j] = has ? kids[j].hi[1] : nan, w.hiz[j] = has ? kids[j].hi[2] : nan;
+        w.c[j] = has ? refs[j] : refs[0];
+    }
+    return (int32_t)at;
+}
+
 }  // namespace
 
 // The per-wave walk queue (bvh_closest_queue) and the leaf list (bvh_closest_postponed) pack `owner lane | reference << 6`
@@ -624,6 +669,7 @@ bool flatten_scene(const pt_camera &cam, const pt_object *objs, uint32_t n_objs,
         BvhMeshRec bm{};
         bm.cx = r.cx, bm.cy = r.cy, bm.cz = r.cz, bm.rr = r.rr;
         bm.root = r.bvh_root;
+        bm.root4 = widen(out.bvh_nodes, r.bvh_root, out.bvh_nodes4);
         out.bvh_meshes.push_back(bm);
     }
     return true;

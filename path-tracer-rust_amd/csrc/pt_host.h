@@ -20,6 +20,7 @@ struct FlatScene {
     std::vector<MatRec> mats;
     std::vector<TriShade> tri_shade;
     std::vector<BvhNode> bvh_nodes;
+    std::vector<BvhNode4> bvh_nodes4;  // the same trees four children wide (two levels folded into one)
     std::vector<SphPairRec> sph_pairs;
     std::vector<FlatPairRec> flat_pairs;
     std::vector<CandPairRec> cand_pairs;  // [0, n_other_pairs): records without a filter

@@ -622,9 +622,9 @@ __host__ __device__ inline size_t pass_cand_nodes_offset(const DevScene &S) {
     return pass_cand_queues_bytes(S) + (size_t)(kBlock / 64u) * kCandWalkKeyBytes;
 }
 __host__ __device__ inline size_t pass_cand_bvh_bytes(const DevScene &S) {
-    return pass_cand_nodes_offset(S) + ((S.bvh_in_lds & 4u) ? (size_t)S.n_bvh_nodes * sizeof(BvhNode) : 0u);
+    return pass_cand_nodes_offset(S) + ((S.bvh_in_lds & 4u) ? (size_t)walk_node_count(S) * sizeof(WalkNode) : 0u);
 }
-static_assert(kCandWalkKeyBytes % 16u == 0u && sizeof(BvhNode) % 16u == 0u, "per-wave areas stay 16-byte aligned");
+static_assert(kCandWalkKeyBytes % 16u == 0u && sizeof(WalkNode) % 16u == 0u, "per-wave areas stay 16-byte aligned");
 
 // (The workgroup's own copy of the nodes in LDS, in front of the stacks, was tried: mesh.json's 141 nodes are 9 KB, which
 // leaves room for three workgroups per CU instead of four - 16.1 against 17.8 G bounces/s.)
@@ -716,11 +716,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
     unsigned long long *p_key = nullptr;
     unsigned long long *walk_keys = nullptr;
     WalkQueue wq{};
-    const BvhNode *const nodes_lds = reinterpret_cast<const BvhNode *>(walk_lds + pass_cand_nodes_offset(S));
+    const WalkNode *const nodes_lds = reinterpret_cast<const WalkNode *>(walk_lds + pass_cand_nodes_offset(S));
     if (BVH && NLDS) {  // a box test of the walk queue then waits for an LDS read instead of a 64-byte gather from L2
-        const uint4 *src = reinterpret_cast<const uint4 *>(S.bvh_nodes);
+        const uint4 *src = reinterpret_cast<const uint4 *>(walk_nodes(S));
         uint4 *dst = reinterpret_cast<uint4 *>(walk_lds + pass_cand_nodes_offset(S));
-        for (uint32_t k = tid; k < S.n_bvh_nodes * (uint32_t)(sizeof(BvhNode) / 16u); k += kBlock) dst[k] = src[k];
+        for (uint32_t k = tid; k < walk_node_count(S) * (uint32_t)(sizeof(WalkNode) / 16u); k += kBlock) dst[k] = src[k];
     }
     if (BVH) {
         walk_keys = reinterpret_cast<unsigned long long *>(walk_lds + pass_cand_queues_bytes(S) + (size_t)(tid >> 6) * kCandWalkKeyBytes);
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
             if constexpr (NLDS)
                 key = walk_deferred_keys(S, nodes_lds, in.o, in.d, wq, p_key[e], walk_keys);
             else
-                key = walk_deferred_keys(S, S.bvh_nodes, in.o, in.d, wq, p_key[e], walk_keys);
+                key = walk_deferred_keys(S, walk_nodes(S), in.o, in.d, wq, p_key[e], walk_keys);
             const uint32_t rank = (uint32_t)key;
             if (rank != 0xffffffffu) {
                 in.pix = lds_pix[word_pix(word)];
@@ -1383,7 +1383,7 @@ __global__ __launch_bounds__(kBlock, CAND ? PT_MEGA_CAND_WAVES : 1) void k_mega(
                 if (BVH) {
                     const bool want = active && bvh_wants(S, cur.o, cur.d, __uint_as_float((uint32_t)(key >> 32)));
                     if (__builtin_amdgcn_ballot_w64(want) != 0ull)  // wave-uniform
-                        key = walk_deferred_keys(S, S.bvh_nodes, cur.o, cur.d, wq, key, walk_keys, want);
+                        key = walk_deferred_keys(S, walk_nodes(S), cur.o, cur.d, wq, key, walk_keys, want);
                 }
                 const uint32_t rank = (uint32_t)key;
                 h.t = __uint_as_float((uint32_t)(key >> 32));

@@ -27,8 +27,8 @@ out = (C.c_ulonglong * 16)()
 L.pt_debug_walk_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 assert L.pt_debug_walk_stats(ctx, out) == 0
 v = list(out)
-names = ["walks", "box_batches", "items", "node_items", "-", "leaf_batches", "leaf_tests", "rays", "parked",
-         "scan_trips", "wave_walks", "overflows", "leaves_live", "walks_won"]
+names = ["walks", "box_batches", "items", "node_items", "popped_live", "leaf_batches", "leaf_tests", "rays", "parked",
+         "scan_trips", "wave_walks", "overflows", "leaves_live", "walks_won", "refills", "popped"]
 for n, x in zip(names, v):
     print("%-16s %d" % (n, x))
 rays = float(v[7])
@@ -42,4 +42,6 @@ print("leaves / walk               %.2f   per leaf batch %.1f" % (v[6] / max(v[0
 print("leaf batches / wave-walk    %.2f" % (v[5] / max(v[10], 1)))
 print("leaves still worth testing    %.3f of those popped" % (v[12] / max(v[6], 1)))
 print("walks that found the hit     %.3f of the walks" % (v[13] / max(v[0], 1)))
+if v[14]:
+    print("pool refills / wave-walk    %.2f   items popped per refill %.1f, still worth testing %.3f" % (v[14] / max(v[10], 1), v[15] / v[14], v[4] / max(v[15], 1)))
 print("batches with dropped pushes %d (%.4f per wave-walk)" % (v[11], v[11] / max(v[10], 1)))
