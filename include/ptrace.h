@@ -187,8 +187,8 @@ int pt_device_free(int device, void *p);
 int pt_device_download(int device, void *dst_host, const void *src_device, size_t bytes);
 
 /* Size limit of one scene's BVHs (pt_ctx_set_scene fails with PT_ERR_INVALID beyond it): the walkers pack a node index or a
- * leaf code (first pair record << 2 | records - 1) into 26 bits of a queue entry - 2^26 nodes, 2^24 pair records (two
- * triangles each) over all BVH meshes of the scene.  1 = fits. */
+ * leaf code (first pair record << 1 | records - 1: a leaf is one or two pair records) into 26 bits of a queue entry - 2^26
+ * nodes, 2^25 pair records (two triangles each) over all BVH meshes of the scene.  1 = fits. */
 int pt_bvh_refs_fit(uint64_t n_bvh_nodes, uint64_t n_pair_records);
 
 /* Device memory the wavefront backend may take for its ray queues in this context (bytes; 0 = the default: 85 % of what

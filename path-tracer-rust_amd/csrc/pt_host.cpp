@@ -423,7 +423,7 @@ bool flatten_scene(const pt_camera &cam, const pt_object *objs, uint32_t n_objs,
                 out.bvh_pair_span = (uint32_t)out.tri_pairs.size() - out.bvh_pair_base;
                 if (!bvh_refs_fit(out.bvh_nodes.size(), out.tri_pairs.size())) {
                     err = "mesh too large for the BVH walkers: node indices and leaf codes are packed into 26 bits of a queue entry "
-                          "(2^26 nodes, 2^24 pair records with leaves of 3-4 records)";
+                          "(2^26 nodes, 2^25 pair records with leaves of two records)";
                     return false;
                 }
             } else {

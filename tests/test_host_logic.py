@@ -136,6 +136,38 @@ static int depth_of(const host::FlatScene &fs, int32_t ref, std::vector<int> &le
     const int a = depth_of(fs, n.c[0], leaf_hits, pair_lo, pair_hi, ok), b = depth_of(fs, n.c[1], leaf_hits, pair_lo, pair_hi, ok);
     return 1 + (a > b ? a : b);
 }
+// the four-wide tree below ref4: every leaf reference it holds, and that each of its boxes is a box of the binary tree
+// (the child boxes of some binary node: collected in `bin_boxes` as lo.x of each, a cheap identity)
+static void walk4(const host::FlatScene &fs, int32_t ref4, std::vector<int32_t> &leaves, bool &ok, int depth, int &deepest) {
+    if (ref4 < 0) { leaves.push_back(ref4); return; }
+    if ((size_t)ref4 >= fs.bvh_nodes4.size() || depth > 64) { ok = false; return; }
+    deepest = depth > deepest ? depth : deepest;
+    const BvhNode4 &n = fs.bvh_nodes4[(size_t)ref4];
+    int live = 0;
+    for (int j = 0; j < 4; ++j) {
+        const bool filler = n.lox[j] != n.lox[j];  // NaN
+        if (filler) {
+            // a filler box is NaN in every bound (never hit: pt_device.h) and repeats child 0's reference; fillers come last
+            if (n.hix[j] == n.hix[j] || n.loy[j] == n.loy[j] || n.hiz[j] == n.hiz[j] || n.c[j] != n.c[0] || j < 2) ok = false;
+            continue;
+        }
+        if (live != j) ok = false;
+        ++live;
+        bool found = false;  // the box is one of the binary tree's child boxes, with the same reference kind
+        for (const BvhNode &b : fs.bvh_nodes)
+            for (int h = 0; h < 2; ++h)
+                if (b.lox[h] == n.lox[j] && b.loy[h] == n.loy[j] && b.loz[h] == n.loz[j] && b.hix[h] == n.hix[j] && b.hiy[h] == n.hiy[j] &&
+                    b.hiz[h] == n.hiz[j] && ((b.c[h] < 0) == (n.c[j] < 0)) && (b.c[h] >= 0 || b.c[h] == n.c[j]))
+                    found = true;
+        if (!found) ok = false;
+        walk4(fs, n.c[j], leaves, ok, depth + 1, deepest);
+    }
+}
+static void leaves2(const host::FlatScene &fs, int32_t ref, std::vector<int32_t> &leaves) {
+    if (ref < 0) { leaves.push_back(ref); return; }
+    leaves2(fs, fs.bvh_nodes[(size_t)ref].c[0], leaves);
+    leaves2(fs, fs.bvh_nodes[(size_t)ref].c[1], leaves);
+}
 int main(int argc, char **argv) {
     pt_scene *sc = nullptr;
     if (pt_scene_load(argv[1], argv[2], &sc) != 0) { printf("FAIL load %s\n", pt_last_error()); return 1; }
@@ -166,6 +198,14 @@ int main(int argc, char **argv) {
         for (uint32_t k = 0; k < n_tris; ++k)
             if (hits[k] != ((k >= r.tri_begin && k < r.tri_begin + r.tri_count) ? 1 : 0)) { printf("FAIL cover %u\n", k); return 1; }
         deepest = (uint32_t)d > deepest ? (uint32_t)d : deepest;
+        // the four-wide form of the same tree (the walk queue's): the same leaves in the same order, each once, every box one
+        // of the binary tree's, at most half as deep (+1)
+        std::vector<int32_t> l2, l4;
+        leaves2(fs, r.bvh_root, l2);
+        int deep4 = 0;
+        walk4(fs, fs.bvh_meshes[q - 1].root4, l4, ok, 1, deep4);
+        if (!ok || l2 != l4 || 2 * deep4 > d + 2) { printf("FAIL four-wide tree %d %zu %zu %d %d\n", (int)ok, l2.size(), l4.size(), deep4, d); return 1; }
+        if (fs.bvh_nodes4.size() * 2 > fs.bvh_nodes.size() + 2) { printf("FAIL four-wide node count %zu %zu\n", fs.bvh_nodes4.size(), fs.bvh_nodes.size()); return 1; }
     }
     if (q != fs.bvh_meshes.size()) { printf("FAIL bvh_meshes count\n"); return 1; }
     if (q != 0 && (fs.bvh_stack < deepest + 1u || fs.bvh_stack > kBvhStack)) { printf("FAIL stack %u %u\n", fs.bvh_stack, deepest); return 1; }
@@ -197,15 +237,15 @@ def test_flatten_tables_of_the_walk_queue(tmp_path):
 
 
 def test_bvh_reference_limit():
-    """The BVH walkers pack a node index or a leaf code (first pair record << 2 | records - 1) into 26 bits of a queue entry
+    """The BVH walkers pack a node index or a leaf code (first pair record << 1 | records - 1: leaves of one or two records) into 26 bits of a queue entry
     (csrc/pt_device.h: WalkQueue, LeafLds); flatten_scene refuses a scene beyond that instead of letting references wrap."""
     L = ptlib.product()
     L.pt_bvh_refs_fit.argtypes = [C.c_uint64, C.c_uint64]
     assert L.pt_bvh_refs_fit(141, 300) == 1                      # mesh.json
     assert L.pt_bvh_refs_fit((1 << 26) - 1, 1000) == 1
     assert L.pt_bvh_refs_fit(1 << 26, 1000) == 0                 # node indices need 27 bits
-    assert L.pt_bvh_refs_fit(1000, (1 << 24) - 1) == 1
-    assert L.pt_bvh_refs_fit(1000, 1 << 24) == 0                 # leaf codes need 27 bits
+    assert L.pt_bvh_refs_fit(1000, (1 << 25) - 1) == 1
+    assert L.pt_bvh_refs_fit(1000, 1 << 25) == 0                 # leaf codes need 27 bits
 
 
 def test_build_flags_are_reported():
