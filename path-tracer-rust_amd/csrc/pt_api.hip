@@ -174,6 +174,11 @@ struct pt_ctx {
     uint32_t mem_share = 1;
     size_t mem_budget = 0;
     double cb_last_ms = 0.0;  // time of the last progress callback of the call in progress (throttle: pt_config.progress_ms)
+    // Passes sized by TIME (k_pass_cand, megakernel rounds): primary samples per millisecond the last timed pass / round of this
+    // scene went through, per backend (0: not measured yet - the next frame starts with a short timed pass).  pt_ctx_set_scene
+    // forgets them.
+    double pass_rate = 0.0, round_rate = 0.0;
+    const char *pass_rate_kernel = nullptr;  // the kernel pass_rate was measured on (flags choose other kernels)
 };
 
 namespace {
@@ -314,7 +319,8 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
     const bool one_kernel = bvh_ok && c->tune.pass_kernel && !(cfg->flags & PT_FLAG_SEPARATE_KERNELS);
     const bool needs_hits = !one_kernel;
     const bool stack_form = one_kernel && c->scene.cand_scan != 0u;
-    const bool stack_park = stack_form && c->scene.n_bvh_nodes != 0u;  // container 1: the waves' parked rays
+    // container 1: the waves' parked rays (scenes with walks) or deferred glass hits
+    const bool stack_park = stack_form && (c->scene.n_bvh_nodes != 0u || c->scene.glass_defer_ok != 0u);
     uint64_t want = cfg->rays_per_pass ? cfg->rays_per_pass : c->tune.rays_per_pass;
     size_t stack_budget = 0;  // stack_form, default pass size: what the streams' stacks may take
     if (!want) {
@@ -409,10 +415,27 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
 
     const uint32_t n_pass = (cfg->spp + spp_pass - 1) / spp_pass;
     const int n_depth = kMaxDepth;  // rays of depth 0..11 exist
+    // PASSES THAT FOLLOW THE SCENE (k_pass_cand at the library's own pass size).  The reference looks at its stop flag every
+    // 100 ms (mod.rs:947-958); here the flag is read between passes, so a pass must not take much longer than that WHATEVER a
+    // ray of the scene costs - 512 Mi primary rays are 0.1 s on cornell.json, 0.15 s on mesh.json and more on dearer scenes.
+    // The first pass of a scene is short (kProbeRays primary rays) and timed (HIP events around the launch); every pass is
+    // timed, and the next one gets as many samples as the measured rate fits into kPassTargetMs (stretched by up to a fifth where that saves a pass) - at most sixteen times the
+    // pass before (a short pass measures launch overheads too), never more than the planned spp_pass (the stacks, the sample
+    // field of the bookkeeping word), the rest of the frame cut into equal passes.  The rate is kept with the context
+    // (pt_ctx.pass_rate), so the following frames of the same scene start at full length: the bench frame is six passes of 683
+    // samples as before.  Frames of at most 2 x kProbeRays primary rays are one pass; an explicit rays_per_pass is taken as
+    // given.  Passes only batch the samples: the image does not depend on them.
+    constexpr uint64_t kProbeRays = 8ull << 20;
+    constexpr double kPassTargetMs = 100.0;
+    const bool adaptive = stack_form && !cfg->rays_per_pass && !c->tune.rays_per_pass && n_pass > 0u &&
+                          (uint64_t)npix * cfg->spp > 2u * kProbeRays;
+    const char *const rate_key = pt_ctx_pass_kernel(c, cfg->flags);
+    double rate = (adaptive && c->pass_rate_kernel == rate_key) ? c->pass_rate : 0.0;
     size_t ev_i = 0;
     hipEvent_t ev_begin = get_event(c, ev_i++), ev_end = get_event(c, ev_i++);
     hipEvent_t pass_done[2] = {get_event(c, ev_i++), get_event(c, ev_i++)};
-    if (!ev_begin || !ev_end || !pass_done[0] || !pass_done[1]) {
+    hipEvent_t pass_begin[2] = {get_event(c, ev_i++), get_event(c, ev_i++)};
+    if (!ev_begin || !ev_end || !pass_done[0] || !pass_done[1] || !pass_begin[0] || !pass_begin[1]) {
         set_error("hipEventCreate failed");
         return PT_ERR_HIP;
     }
@@ -426,10 +449,18 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
     // the cancel byte is read at EVERY pass boundary (the reference polls it every 100 ms, mod.rs:947-958).
     const double cb_every_ms = cfg->progress_ms == PT_PROGRESS_EVERY_PASS ? 0.0 : (cfg->progress_ms ? (double)cfg->progress_ms : 500.0);
     double &cb_last_ms = c->cb_last_ms;  // (set when the call began: pt_ctx_render; a call rendered in parts keeps one clock)
-    for (uint32_t p = 0; p < n_pass; ++p) {
+    uint32_t s_next = 0u, s_prev = 0u;  // samples of a pixel issued so far / in the pass before
+    for (uint32_t p = 0; s_next < cfg->spp; ++p) {
         // keep two passes in flight; k_pass_cand's long passes (0.1 s) one - the cancel flag is looked at when a pass ends, and
         // the few microseconds between two launches are nothing against such a pass
-        if (stack_form && p >= 1) HIP_TRY(hipEventSynchronize(pass_done[(p - 1) & 1]));
+        if (stack_form && p >= 1) {
+            HIP_TRY(hipEventSynchronize(pass_done[(p - 1) & 1]));
+            if (adaptive) {
+                float ms = 0.0f;
+                HIP_TRY(hipEventElapsedTime(&ms, pass_begin[(p - 1) & 1], pass_done[(p - 1) & 1]));
+                if (ms > 0.0f) rate = (double)npix * s_prev / ms;
+            }
+        }
         if (p >= 2) HIP_TRY(hipEventSynchronize(pass_done[p & 1]));
         if (cancel && *cancel) {
             cancelled = true;
@@ -439,16 +470,31 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
             const double t_now = now_ms();
             if (t_now - cb_last_ms >= cb_every_ms) {
                 cb_last_ms = t_now;
-                cb(user, (float)(stack_form ? p : p - 1u) / (float)n_pass);  // (the passes known to be done)
+                // (the samples known to be done)
+                cb(user, stack_form ? (float)s_next / (float)cfg->spp : (float)(p - 1u) / (float)n_pass);
                 if (cancel && *cancel) {  // raised from inside the callback
                     cancelled = true;
                     break;
                 }
             }
         }
-        const uint32_t s0 = p * spp_pass;
-        const uint32_t s_here = (cfg->spp - s0) < spp_pass ? (cfg->spp - s0) : spp_pass;
+        const uint32_t s0 = s_next;
+        uint32_t s_here = (cfg->spp - s0) < spp_pass ? (cfg->spp - s0) : spp_pass;
+        if (adaptive) {
+            uint64_t fit = rate > 0.0 ? (uint64_t)(rate * kPassTargetMs / (double)npix) : kProbeRays / npix;
+            if (s_prev && fit > 16ull * s_prev) fit = 16ull * s_prev;
+            if (fit < 1u) fit = 1u;
+            if (fit > spp_pass) fit = spp_pass;
+            // the rest of the frame in equal passes, each up to a fifth longer than the target rather than one pass more
+            uint64_t stretch = fit + fit / 5u;
+            if (stretch > spp_pass) stretch = spp_pass;
+            const uint32_t left = cfg->spp - s0, n_left = (uint32_t)((left + stretch - 1u) / stretch);
+            s_here = (left + n_left - 1u) / n_left;
+        }
+        s_next = s0 + s_here;
+        s_prev = s_here;
         c->live_spp_issued = s0 + s_here;
+        if (adaptive) HIP_TRY(hipEventRecord(pass_begin[p & 1], st));
         if (one_kernel) {  // the whole pass in one launch (k_pass)
             hipEvent_t a = nullptr, b = nullptr;
             if (c->profiling) {
@@ -498,6 +544,13 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev_end, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (adaptive && passes_done != 0u) {  // the last pass counts too (a frame of one probe and one long pass would otherwise only know the probe)
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, pass_begin[(passes_done - 1u) & 1u], pass_done[(passes_done - 1u) & 1u]));
+        if (ms > 0.0f && (double)npix * s_prev >= (double)kProbeRays) rate = (double)npix * s_prev / ms;
+        c->pass_rate = rate;
+        c->pass_rate_kernel = rate_key;
+    }
     std::vector<unsigned long long> rays(K);
     HIP_TRY(hipMemcpy(rays.data(), c->blk_rays.p, K * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     uint32_t flags = 0;
@@ -509,12 +562,7 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
         stats->intersect_rays = total;
         stats->intersect_launches = one_kernel ? passes_done : passes_done * (uint32_t)n_depth;
         stats->passes = passes_done;
-        uint64_t smp = 0;
-        for (uint32_t p = 0; p < passes_done; ++p) {
-            const uint32_t s0 = p * spp_pass;
-            smp += npix * ((cfg->spp - s0) < spp_pass ? (cfg->spp - s0) : spp_pass);
-        }
-        stats->samples = smp;
+        stats->samples = npix * (uint64_t)s_next;  // (every pass that was issued has run: the stream is synchronised)
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, ev_begin, ev_end));
         stats->ms_device = ms;
@@ -564,9 +612,17 @@ int render_mega(pt_ctx *c, const pt_config *cfg, const FrameParams &F, hipStream
     while ((uint64_t)npix * n_split < 4 * lanes && n_split < round_spp) n_split *= 2;
     if (n_split > round_spp) n_split = round_spp;
     const uint32_t n_rounds = (cfg->spp + round_spp - 1) / round_spp;
+    // rounds that follow the scene, as the wavefront's passes do (render_wavefront): a short timed first round, then as many
+    // samples per round as the measured rate fits into 100 ms (+ a fifth) (at most 16 x the round before, at most round_spp), the rest
+    // of the frame in equal rounds, one launch in flight; the rate stays with the context for the next frame
+    constexpr uint64_t kProbeSamples = 4ull << 20;
+    constexpr double kRoundTargetMs = 100.0;
+    const bool adaptive = !cfg->rays_per_pass && (uint64_t)npix * cfg->spp > 2u * kProbeSamples;
+    double rate = adaptive ? c->round_rate : 0.0;
     hipEvent_t ev_begin = get_event(c, 0), ev_end = get_event(c, 1);
     hipEvent_t round_done[2] = {get_event(c, 2), get_event(c, 3)};
-    if (!ev_begin || !ev_end || !round_done[0] || !round_done[1]) {
+    hipEvent_t round_begin[2] = {get_event(c, 4), get_event(c, 5)};
+    if (!ev_begin || !ev_end || !round_done[0] || !round_done[1] || !round_begin[0] || !round_begin[1]) {
         set_error("hipEventCreate failed");
         return PT_ERR_HIP;
     }
@@ -576,25 +632,45 @@ int render_mega(pt_ctx *c, const pt_config *cfg, const FrameParams &F, hipStream
     bool cancelled = false;
     uint32_t rounds_done = 0;
     uint64_t samples = 0;
-    for (uint32_t r = 0; r < n_rounds; ++r) {
+    uint32_t s_next = 0u, s_prev = 0u;
+    for (uint32_t r = 0; s_next < cfg->spp; ++r) {
+        if (adaptive && r >= 1) {  // one launch in flight: its time sizes the next
+            HIP_TRY(hipEventSynchronize(round_done[(r - 1) & 1]));
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, round_begin[(r - 1) & 1], round_done[(r - 1) & 1]));
+            if (ms > 0.0f) rate = (double)npix * s_prev / ms;
+        }
         if (r >= 2) HIP_TRY(hipEventSynchronize(round_done[r & 1]));  // two launches in flight
         if (cancel && *cancel) {
             cancelled = true;
             break;
         }
-        if (cb && r >= 2) {
+        if (cb && r >= (adaptive ? 1u : 2u)) {
             const double t_now = now_ms();
             if (t_now - cb_last_ms >= cb_every_ms) {
                 cb_last_ms = t_now;
-                cb(user, (float)(r - 1) / (float)n_rounds);
+                cb(user, adaptive ? (float)s_next / (float)cfg->spp : (float)(r - 1) / (float)n_rounds);
                 if (cancel && *cancel) {
                     cancelled = true;
                     break;
                 }
             }
         }
-        const uint32_t s0 = r * round_spp;
-        const uint32_t s_here = (cfg->spp - s0) < round_spp ? (cfg->spp - s0) : round_spp;
+        const uint32_t s0 = s_next;
+        uint32_t s_here = (cfg->spp - s0) < round_spp ? (cfg->spp - s0) : round_spp;
+        if (adaptive) {
+            uint64_t fit = rate > 0.0 ? (uint64_t)(rate * kRoundTargetMs / (double)npix) : kProbeSamples / npix;
+            if (s_prev && fit > 16ull * s_prev) fit = 16ull * s_prev;
+            if (fit < 1u) fit = 1u;
+            if (fit > round_spp) fit = round_spp;
+            uint64_t stretch = fit + fit / 5u;
+            if (stretch > round_spp) stretch = round_spp;
+            const uint32_t left = cfg->spp - s0, n_left = (uint32_t)((left + stretch - 1u) / stretch);
+            s_here = (left + n_left - 1u) / n_left;
+            HIP_TRY(hipEventRecord(round_begin[r & 1], st));
+        }
+        s_next = s0 + s_here;
+        s_prev = s_here;
         const uint32_t split = n_split < s_here ? n_split : s_here;
         const uint32_t lane_spp = (s_here + split - 1) / split;
         const uint64_t items = npix * split;
@@ -610,6 +686,12 @@ int render_mega(pt_ctx *c, const pt_config *cfg, const FrameParams &F, hipStream
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev_end, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (adaptive && rounds_done != 0u) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, round_begin[(rounds_done - 1u) & 1u], round_done[(rounds_done - 1u) & 1u]));
+        if (ms > 0.0f && (double)npix * s_prev >= (double)kProbeSamples) rate = (double)npix * s_prev / ms;
+        c->round_rate = rate;
+    }
     if (stats) {
         unsigned long long total = 0;
         HIP_TRY(hipMemcpy(&total, c->total_rays.p, sizeof total, hipMemcpyDeviceToHost));
@@ -809,7 +891,11 @@ int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uin
     c->scene.n_other_pairs = fs.n_other_pairs;
     c->scene.n_flat_exact = fs.n_flat_exact;
     c->scene.nodes_in_lds_ok = c->tune.nodes_lds ? 1u : 0u;
-    c->scene.glass_defer_ok = c->tune.glass_defer ? 1u : 0u;
+    {  // glass deferral only where there is glass to defer
+        bool has_glass = false;
+        for (uint32_t i = 0; i < n_objs; ++i) has_glass = has_glass || objs[i].reflect_type == PT_REFRACT;
+        c->scene.glass_defer_ok = (c->tune.glass_defer && has_glass) ? 1u : 0u;
+    }
     c->cand_ok = fs.cand_ok;
     c->scene.cand_staged = 0u;
     c->scene.surf_staged = 0u;
@@ -858,6 +944,8 @@ int pt_ctx_set_scene(pt_ctx *c, const pt_camera *cam, const pt_object *objs, uin
             host::mesh_bounding_box(tris + objs[i].tri_offset, objs[i].tri_count, &c->h_boxes[(size_t)12 * i]);
     c->boxes_dirty = true;
     c->has_scene = true;
+    c->pass_rate = c->round_rate = 0.0;  // (another scene: the passes' length is measured again)
+    c->pass_rate_kernel = nullptr;
     return PT_OK;
 }
 

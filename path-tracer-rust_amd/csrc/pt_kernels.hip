@@ -59,12 +59,12 @@ static_assert(pass_acc_slots(1) == 4u && pass_acc_slots(2) == 6u && (pass_acc_sl
 
 // k_pass_cand LDS: [accumulators, tails, pixel indices as k_pass][per wave: float4 ray_a [128] | u64 key [128] |
 // float2 ray_b [128] | u16 ring [kCandQueueCap]][staged candidate records]
-// (with glass deferral: kCandDeferCap entries per wave before them; a wave shades its deferred glass hits as soon as
-// kCandDeferFlush are waiting, so 31 left over + 64 new fit)
-constexpr uint32_t kCandDeferCap = 96, kCandDeferFlush = 32;
-__host__ __device__ constexpr size_t pass_lds_cand_offset(uint32_t m, bool defer) {
-    return pass_lds_defer_offset(m) + (defer ? (size_t)(kBlock / 64u) * 3u * kCandDeferCap * sizeof(float4) : 0u);
-}
+// Glass deferral (DEFER): the glass hits of a wave wait in the wave's PARKING AREA in global memory - the ray (40 B) and its hit
+// (distance, rank: 8 B), where scenes with BVH meshes park the rays that have to walk - until 64 of them make a dense wave.
+// (Rounds 2-3 kept them in LDS: 18 KB per workgroup for 96 entries per wave, flushed at 32 - half-full batches, and with
+// the levels gone the pushes and flushes cost what the batches saved.)
+constexpr uint32_t kCandDeferFlush = 64;
+__host__ __device__ constexpr size_t pass_lds_cand_offset(uint32_t m, bool /*defer*/) { return pass_lds_defer_offset(m); }
 constexpr size_t kCandWaveBytes = 128u * 16u + 128u * 8u + 128u * 8u + kCandQueueCap * 2u;  // 4480
 __host__ __device__ constexpr size_t pass_lds_cand_bytes() { return (size_t)(kBlock / 64u) * kCandWaveBytes; }
 static_assert(kCandWaveBytes % 16u == 0u, "per-wave areas stay 16-byte aligned");
@@ -768,8 +768,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
     qs.base = q0.buf + (size_t)(b * 4u + wv) * cap_w * kRayBytes;
     qs.off_tp = room * 16u;
     qs.off_od1 = room * 32u;
-    StreamSlice qpark{};  // BVH: the parked rays of the wave (container 1)
-    if (BVH) {
+    StreamSlice qpark{};  // BVH: the parked rays of the wave (container 1); DEFER: its glass hits
+    if (BVH || DEFER) {
         qpark.base = q1.buf + (size_t)(b * 4u + wv) * kWaveParkBytes;
         qpark.off_tp = kCandParkCap * 16u;
         qpark.off_od1 = kCandParkCap * 32u;
@@ -799,9 +799,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
             store_ray(qs, wbase + c1 + lane_prefix(m2), so.x, so.d1, so.thr1,
                       pack_word(word_pix(word), word_sample(word), meta_depth(so.meta1), meta_branch(so.meta1)));
     };
-    // glass hits of this wave wait in LDS until kCandDeferFlush of them make a dense wave (see k_pass)
-    float4 *const dbuf = reinterpret_cast<float4 *>(reinterpret_cast<char *>(dyn_lds) + pass_lds_defer_offset(m)) +
-                         (size_t)(tid >> 6) * (3u * kCandDeferCap);
+    // DEFER: glass hits of this wave wait in its parking area until kCandDeferFlush of them make a dense wave
     uint32_t n_defer = 0;  // wave-uniform
     auto shade_deferred = [&](uint32_t e, bool valid) {
         ShadeOut so;
@@ -809,16 +807,15 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
         so.emits = false;
         uint32_t word = 0;
         PT_PHASE(kPhDefer);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the wave's own stores, read back by other lanes)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (valid) {
-            const float4 a = dbuf[e], bq = dbuf[kCandDeferCap + e], cq = dbuf[2u * kCandDeferCap + e];
             PathRay in;
-            in.o = mk(a.x, a.y, a.z);
-            in.d = mk(a.w, bq.x, bq.y);
-            in.thr = mk(bq.z, bq.w, cq.x);
-            word = __float_as_uint(cq.y);
+            load_ray_slice(qpark, e, in.o, in.d, in.thr, word);
+            const unsigned long long hk = p_key[e];  // (distance bits << 32) | rank, as parked
             in.pix = lds_pix[word_pix(word)];
             in.meta = pack_meta(s0 + word_sample(word), word_depth(word), word_branch(word));
-            const Surface sf = fetch_surface_rank(cand.surf, in.o, in.d, cq.z, __float_as_uint(cq.w));  // (t, rank) as parked
+            const Surface sf = fetch_surface_rank(cand.surf, in.o, in.d, __uint_as_float((uint32_t)(hk >> 32)), (uint32_t)hk);
             shade_surface<kShadeRefractOnly>(P, in, sf, so);
             PT_PHASE(kPhEmit);
             if (so.emits) add_radiance_lds(lds_acc, m, word_pix(word), so.contrib);
@@ -1016,9 +1013,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
             if (DEFER && md != 0ull) {
                 if (so.deferred) {
                     const uint32_t e = n_defer + lane_prefix(md);
-                    dbuf[e] = make_float4(pr.o.x, pr.o.y, pr.o.z, pr.d.x);
-                    dbuf[kCandDeferCap + e] = make_float4(pr.d.y, pr.d.z, pr.thr.x, pr.thr.y);
-                    dbuf[2u * kCandDeferCap + e] = make_float4(pr.thr.z, __uint_as_float(prev_word), hit_t, __uint_as_float(hit_rank));
+                    store_ray(qpark, e, pr.o, pr.d, pr.thr, prev_word);
+                    p_key[e] = ((unsigned long long)__float_as_uint(hit_t) << 32) | hit_rank;
                 }
                 n_defer = rfl(n_defer + (uint32_t)__builtin_popcountll(md));
             }
@@ -1729,7 +1725,7 @@ hipError_t launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const Fram
         // anyway - shading it in place, 46.5 against 46.05 G bounces/s on cornell, builds alternated; PT_GLASS_DEFER=1 brings
         // the buffers back for that comparison.  Five waves per SIMD in the LDS this frees: 96 VGPRs with 91 values spilled,
         // 26.3 G.)
-        const bool defer = !bvh && S.glass_defer_ok && pass_lds_cand_offset(m, true) + pass_lds_cand_bytes() <= budget;
+        const bool defer = !bvh && S.glass_defer_ok;  // (the scene has glass and the context holds parking areas: pt_api.hip)
         // walks: the nodes of a small tree are staged in LDS beside (smaller) walk queues when they fit with the candidate
         // records (mesh.json: 171 nodes, 10.9 KB: up to 24 pixels per stream).  Measured: no gain and no loss against the
         // gathers from L2 (26.74 / 26.72 G bounces/s) - a box-test batch waits for its turn at the SIMD, not for its node -

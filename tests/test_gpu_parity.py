@@ -1246,6 +1246,84 @@ def test_cancel_mid_frame_and_progress_cadence(gpu, backend):
     assert L.pt_device_free(0, d_out) == 0
 
 
+def _dear_scene():
+    """A room whose rays cost several times cornell's: 56 small tilted meshes of 14 triangles each (no BVH below 16; tilted, so
+    no conservative filter applies) = 392 pair records that are candidates of EVERY ray, under an emissive sphere."""
+    rng = np.random.default_rng(17)
+    objs, tris = [], []
+    for i in range(56):
+        c = rng.uniform(-2.0, 2.0, 3).astype(np.float32)
+        tl = []
+        for _ in range(14):
+            a = rng.uniform(-0.3, 0.3, 3)
+            tl.append(ptlib.make_tri(a, a + rng.uniform(-0.25, 0.25, 3), a + rng.uniform(-0.25, 0.25, 3)))
+        objs.append(ptlib.make_mesh(c, rng.uniform(0.3, 0.9, 3), (0, 0, 0), "Diffuse", len(tris), len(tl), (0, 0, 0), 1.0))
+        tris.extend(tl)
+    objs.append(ptlib.make_sphere((0, 0, 0), 9.0, (0.8, 0.8, 0.8), (0.7, 0.7, 0.7), "Diffuse"))
+    cam = ptlib.make_camera((0.0, 0.0, 7.0), (0.0, 0.0, -1.0))
+    return ptlib.Scene("dear", cam, objs, tris)
+
+
+@pytest.mark.parametrize("backend", [0, 1])
+def test_cancel_latency_follows_the_scene(gpu, backend):
+    """The reference looks at its stop flag every 100 ms (mod.rs:947-958); here it is read between passes / rounds, whose
+    length is measured - a short timed first pass, then as many samples as fit 100-120 ms - instead of a constant tuned on the
+    bench scene.  On a scene several times dearer per ray than cornell.json, at the library's own pass size, a flag raised
+    from another thread in the middle of a frame of many seconds brings the call back within 250 ms, with the samples that
+    were accumulated: the frame of `done` samples per pixel, bit for bit."""
+    import threading
+    import time
+
+    L, ctx = gpu
+    sc = _dear_scene()
+    set_scene(gpu, sc)
+    w, h, spp = 768, 512, 8192  # 3.2 G primary samples: many seconds on this scene
+    npix = w * h
+    d_out = C.c_void_p()
+    assert L.pt_device_malloc(0, npix * 12, C.byref(d_out)) == 0
+
+    def download():
+        host = np.zeros((npix, 3), dtype=np.float32)
+        assert L.pt_device_download(0, host.ctypes.data_as(C.c_void_p), d_out, npix * 12) == 0
+        return host
+
+    flag = (C.c_uint8 * 1)(0)
+    t_raised = [0.0]
+
+    def raise_later():
+        time.sleep(0.6)
+        t_raised[0] = time.perf_counter()
+        flag[0] = 1
+
+    cfg = PtConfig(w, h, spp, backend, 9, 0, 0, 0, 0)  # rays_per_pass = 0: the library's own pass size
+    st = PtStats()
+    th = threading.Thread(target=raise_later)
+    th.start()
+    rc = L.pt_ctx_render(ctx, C.byref(cfg), d_out, None, C.cast(flag, C.c_void_p), None, None, C.byref(st))
+    t_back = time.perf_counter()
+    th.join()
+    assert rc == ptlib.PT_CANCELLED, (rc, L.pt_last_error())
+    latency = t_back - t_raised[0]
+    assert 0.0 <= latency < 0.25, latency
+    assert st.samples % npix == 0
+    done = st.samples // npix
+    assert 0 < done < spp and st.passes >= 3  # a short timed pass, then passes of about a tenth of a second
+    part = download()
+    # the same samples in ONE pass (an explicit pass size): same bits, same bounce count - passes only batch the samples
+    cfg2 = PtConfig(w, h, done, backend, 9, 0, 0, min(npix * done, 0xffffffff), 0)
+    st2 = PtStats()
+    assert L.pt_ctx_render(ctx, C.byref(cfg2), d_out, None, None, None, None, C.byref(st2)) == 0, L.pt_last_error()
+    assert st2.ray_bounces == st.ray_bounces and np.array_equal(part, download())
+    # the passes' length was learnt: the same frame again starts at full length (fewer passes for the same samples)
+    cfg3 = PtConfig(w, h, done, backend, 9, 0, 0, 0, 0)
+    st3 = PtStats()
+    assert L.pt_ctx_render(ctx, C.byref(cfg3), d_out, None, None, None, None, C.byref(st3)) == 0, L.pt_last_error()
+    assert st3.passes <= st.passes and st3.ray_bounces == st.ray_bounces and np.array_equal(part, download())
+    per_pass_ms = st3.ms_device / st3.passes
+    assert per_pass_ms < 160.0, per_pass_ms
+    assert L.pt_device_free(0, d_out) == 0
+
+
 def _pixels_against_oracle(gpu, sc, w, h, spp, seed, pixels, backend=0):
     """Render the image rows that hold `pixels` on the GPU (bands: the RNG is keyed on the global pixel index, so a band
     is the frame's own pixels) and compare those pixels with the oracle's render_pixel (mod.rs:794-857)."""
