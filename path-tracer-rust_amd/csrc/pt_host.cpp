@@ -722,7 +722,34 @@ int plan_pass(const PassPlanIn &in, PassPlan &out, uint64_t *want_next) {
     // one for which that is smallest (cornell 1024x768: m = 21 -> 24, 37 450 streams in 36.6 rounds -> 32 768 in 32.0,
     // 37.3 -> 37.7 G bounces/s).  Not for scenes with walks, whose streams differ too much in length for rounds to show
     // (mesh.json: 24.0 rounds are slower than 25.6).
-    if (in.cand_scan && !in.has_bvh && !in.streams && in.n_cus != 0u && m >= 8u) {
+    // SMALL FRAMES (round 4: the reference's own sizes - its launch configuration is 450x300 @500, .vscode/launch.json).  When
+    // the tuned stream size gives the launch fewer than sixteen rounds of resident workgroups, what a launch takes is
+    // ceil(K / resident) x m to a good approximation, and a last round that is mostly empty costs a whole round: 450x300
+    // @500 at the tuned size is 2 756 streams of 49 pixels = 2.7 rounds, mesh.json 21.3 G bounces/s; 4 120 streams of 33
+    // pixels = 4.02 rounds: 26.2; 5 493 of 25 = 5.4 rounds: 23.6; 8 240 of 17 = 8.05: 25.0 (cornell.json: 42.1 / 43.0 / 43.2 /
+    // 43.8 - the same order, flatter).  So among the stream sizes from a quarter of the tuned one up to it, the one with the
+    // least ceil(K / resident) x m; of equals the longer streams where rays walk (their streams differ most in length), the
+    // shorter ones otherwise.
+    bool small_frame = false;
+    if (in.stack_form && !in.streams && in.n_cus != 0u && m >= 4u) {
+        const uint64_t resident = (uint64_t)in.n_cus * 4u;
+        const uint64_t k_tuned = (npix + m - 1u) / m;
+        if ((k_tuned + resident - 1u) / resident < 16u) {
+            small_frame = true;
+            uint32_t best_m = m;
+            uint64_t best_cost = ~0ull;
+            for (uint32_t mm = m / 4u ? m / 4u : 1u; mm <= m; ++mm) {
+                const uint64_t kk = (npix + mm - 1u) / mm;
+                const uint64_t cost = ((kk + resident - 1u) / resident) * mm;
+                if (cost < best_cost || (cost == best_cost && in.has_bvh)) {
+                    best_cost = cost;
+                    best_m = mm;
+                }
+            }
+            m = best_m;
+        }
+    }
+    if (!small_frame && in.cand_scan && !in.has_bvh && !in.streams && in.n_cus != 0u && m >= 8u) {
         const uint64_t resident = (uint64_t)in.n_cus * 4u;
         uint32_t best_m = m;
         uint64_t best_cost = ~0ull;
