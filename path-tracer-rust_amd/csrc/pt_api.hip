@@ -85,6 +85,7 @@ struct Tuning {
                                  // would fit its LDS (A/B)
     uint32_t wave_stack = 0;     // PT_WAVE_STACK=n: k_pass_cand's stacks hold n slots (a power of two, 512 <= n < kWaveStackMax)
                                  // instead of kWaveStackMax - the waves then have to hold their primaries back (tests)
+    uint32_t mega_items = 0;     // PT_MEGA_ITEMS=n: the megakernel cuts a round into n items per lane the chip holds (0 = default)
     uint32_t debug = 0;
 };
 static Tuning read_tuning() {
@@ -106,6 +107,10 @@ static Tuning read_tuning() {
     t.rays_per_pass = (uint64_t)num("PT_RAYS_PER_PASS", 0);
     t.nodes_lds = num("PT_NODES_LDS", 1) != 0;
     t.glass_defer = num("PT_GLASS_DEFER", 0) != 0;
+    {
+        const long long mi = num("PT_MEGA_ITEMS", 0);
+        t.mega_items = mi > 0 && mi <= 4096 ? (uint32_t)mi : 0u;
+    }
     {
         const long long ws = num("PT_WAVE_STACK", 0);
         if (ws >= 512 && ws < (long long)kWaveStackMax && (ws & (ws - 1)) == 0) t.wave_stack = (uint32_t)ws;
@@ -417,18 +422,22 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
     const int n_depth = kMaxDepth;  // rays of depth 0..11 exist
     // PASSES THAT FOLLOW THE SCENE (k_pass_cand at the library's own pass size).  The reference looks at its stop flag every
     // 100 ms (mod.rs:947-958); here the flag is read between passes, so a pass must not take much longer than that WHATEVER a
-    // ray of the scene costs - 512 Mi primary rays are 0.1 s on cornell.json, 0.15 s on mesh.json and more on dearer scenes.
-    // The first pass of a scene is short (kProbeRays primary rays) and timed (HIP events around the launch); every pass is
-    // timed, and the next one gets as many samples as the measured rate fits into kPassTargetMs (stretched by up to a fifth where that saves a pass) - at most sixteen times the
-    // pass before (a short pass measures launch overheads too), never more than the planned spp_pass (the stacks, the sample
-    // field of the bookkeeping word), the rest of the frame cut into equal passes.  The rate is kept with the context
-    // (pt_ctx.pass_rate), so the following frames of the same scene start at full length: the bench frame is six passes of 683
-    // samples as before.  Frames of at most 2 x kProbeRays primary rays are one pass; an explicit rays_per_pass is taken as
-    // given.  Passes only batch the samples: the image does not depend on them.
-    constexpr uint64_t kProbeRays = 8ull << 20;
+    // ray of the scene costs - 512 Mi primary rays are 0.1 s on cornell.json, 0.15 s on mesh.json, and a scene of 392
+    // unfiltered candidate records inside an emitting sphere (tests) is fifty times dearer per primary ray.  Nothing is known
+    // about a scene's cost before its first rays have been traced, so the first pass of a scene is TINY (kProbeRays primary
+    // rays: a fraction of a millisecond on the bench scene) and timed (HIP events around the launch); every pass is timed,
+    // and the next one gets as many samples as the measured rate fits into kPassTargetMs (stretched by up to a fifth where
+    // that saves a pass) - at most sixteen times the pass before (a short pass measures launch overheads too, and its
+    // streams are too short to be efficient: the estimate errs towards short passes), never more than the planned spp_pass
+    // (the stacks, the sample field of the bookkeeping word), the rest of the frame cut into equal passes.  The rate is kept
+    // with the context (pt_ctx.pass_rate), so the following frames of the same scene start at full length: the bench frame
+    // is six passes of 683 samples as before, and the first frame of a scene pays three short passes (a few milliseconds).
+    // Frames of at most kAdaptiveMinRays primary rays are one pass; an explicit rays_per_pass is taken as given.  Passes
+    // only batch the samples: the image does not depend on them.
+    constexpr uint64_t kProbeRays = 1ull << 20, kAdaptiveMinRays = 4ull << 20;
     constexpr double kPassTargetMs = 100.0;
     const bool adaptive = stack_form && !cfg->rays_per_pass && !c->tune.rays_per_pass && n_pass > 0u &&
-                          (uint64_t)npix * cfg->spp > 2u * kProbeRays;
+                          (uint64_t)npix * cfg->spp > kAdaptiveMinRays;
     const char *const rate_key = pt_ctx_pass_kernel(c, cfg->flags);
     double rate = (adaptive && c->pass_rate_kernel == rate_key) ? c->pass_rate : 0.0;
     size_t ev_i = 0;
@@ -547,7 +556,7 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
     if (adaptive && passes_done != 0u) {  // the last pass counts too (a frame of one probe and one long pass would otherwise only know the probe)
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, pass_begin[(passes_done - 1u) & 1u], pass_done[(passes_done - 1u) & 1u]));
-        if (ms > 0.0f && (double)npix * s_prev >= (double)kProbeRays) rate = (double)npix * s_prev / ms;
+        if (ms > 0.0f && (double)npix * s_prev >= 16.0 * (double)kProbeRays) rate = (double)npix * s_prev / ms;
         c->pass_rate = rate;
         c->pass_rate_kernel = rate_key;
     }
@@ -589,11 +598,11 @@ int render_mega(pt_ctx *c, const pt_config *cfg, const FrameParams &F, hipStream
                 pt_progress_fn cb, void *user, pt_stats *stats) {
     const uint64_t npix = F.npix;
     int rc;
-    if ((rc = c->acc.ensure(3 * npix)) || (rc = c->total_rays.ensure(1))) return rc;
+    if ((rc = c->acc.ensure(3 * npix)) || (rc = c->total_rays.ensure(16))) return rc;
     c->live_streams = 1;  // accumulators in pixel order
     c->live_m = (uint32_t)npix;
     HIP_TRY(hipMemsetAsync(c->acc.p, 0, 3 * npix * sizeof(unsigned long long), st));
-    HIP_TRY(hipMemsetAsync(c->total_rays.p, 0, sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(c->total_rays.p, 0, 16 * sizeof(unsigned long long), st));
     // The frame is cut into ROUNDS: one round = every pixel of the call x round_spp consecutive samples, one launch (a
     // lane = one pixel's samples of the round, walked one after the other).  A round is sized to about a tenth of a
     // second of work, so the cancel byte and the progress callback are served between launches (the reference polls
@@ -609,15 +618,19 @@ int render_mega(pt_ctx *c, const pt_config *cfg, const FrameParams &F, hipStream
     if (round_spp64 > cfg->spp) round_spp64 = cfg->spp;
     const uint32_t round_spp = (uint32_t)round_spp64;
     uint32_t n_split = 1;  // lanes per pixel within a round
-    while ((uint64_t)npix * n_split < 4 * lanes && n_split < round_spp) n_split *= 2;
+    // (k_mega_cand hands its items out dynamically: finer ones - 8 per lane the chip holds, cornell 41.3 G bounces/s; 4: 39.1,
+    // 16: 40.5, 32: 38.4 - so that a launch's last items are a small part of it; PT_MEGA_ITEMS for A/B runs and tests)
+    const uint64_t item_mult = c->tune.mega_items ? c->tune.mega_items : (mega_uses_cand(c->scene) ? 8u : 4u);
+    const uint64_t want_items = item_mult * lanes;
+    while ((uint64_t)npix * n_split < want_items && n_split < round_spp) n_split *= 2;
     if (n_split > round_spp) n_split = round_spp;
     const uint32_t n_rounds = (cfg->spp + round_spp - 1) / round_spp;
     // rounds that follow the scene, as the wavefront's passes do (render_wavefront): a short timed first round, then as many
     // samples per round as the measured rate fits into 100 ms (+ a fifth) (at most 16 x the round before, at most round_spp), the rest
     // of the frame in equal rounds, one launch in flight; the rate stays with the context for the next frame
-    constexpr uint64_t kProbeSamples = 4ull << 20;
+    constexpr uint64_t kProbeSamples = 1ull << 20, kAdaptiveMinSamples = 4ull << 20;
     constexpr double kRoundTargetMs = 100.0;
-    const bool adaptive = !cfg->rays_per_pass && (uint64_t)npix * cfg->spp > 2u * kProbeSamples;
+    const bool adaptive = !cfg->rays_per_pass && (uint64_t)npix * cfg->spp > kAdaptiveMinSamples;
     double rate = adaptive ? c->round_rate : 0.0;
     hipEvent_t ev_begin = get_event(c, 0), ev_end = get_event(c, 1);
     hipEvent_t round_done[2] = {get_event(c, 2), get_event(c, 3)};
@@ -677,7 +690,9 @@ int render_mega(pt_ctx *c, const pt_config *cfg, const FrameParams &F, hipStream
         const uint64_t grid64 = (items + kBlock - 1) / kBlock;
         const uint64_t max_grid = (uint64_t)prop.multiProcessorCount * 8u;
         const uint32_t grid = (uint32_t)(grid64 < max_grid ? grid64 : max_grid);
-        launch_mega(st, grid ? grid : 1u, c->scene, F, c->acc.p, s0, s0 + s_here, lane_spp, split, c->total_rays.p);
+        if (mega_uses_cand(c->scene) && (rc = c->q_buf[0].ensure(mega_stack_mem_bytes(grid ? grid : 1u)))) return rc;  // split stacks
+        HIP_TRY(hipMemsetAsync(c->total_rays.p + 7, 0, sizeof(unsigned long long), st));  // k_mega_cand's item counter
+        launch_mega(st, grid ? grid : 1u, c->scene, F, c->acc.p, s0, s0 + s_here, lane_spp, split, c->total_rays.p, c->q_buf[0].p);
         HIP_TRY(hipEventRecord(round_done[r & 1], st));
         c->live_spp_issued = s0 + s_here;
         samples += npix * s_here;
@@ -689,12 +704,25 @@ int render_mega(pt_ctx *c, const pt_config *cfg, const FrameParams &F, hipStream
     if (adaptive && rounds_done != 0u) {
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, round_begin[(rounds_done - 1u) & 1u], round_done[(rounds_done - 1u) & 1u]));
-        if (ms > 0.0f && (double)npix * s_prev >= (double)kProbeSamples) rate = (double)npix * s_prev / ms;
+        if (ms > 0.0f && (double)npix * s_prev >= 16.0 * (double)kProbeSamples) rate = (double)npix * s_prev / ms;
         c->round_rate = rate;
     }
     if (stats) {
-        unsigned long long total = 0;
-        HIP_TRY(hipMemcpy(&total, c->total_rays.p, sizeof total, hipMemcpyDeviceToHost));
+        unsigned long long total2[16] = {0};
+        HIP_TRY(hipMemcpy(total2, c->total_rays.p, sizeof total2, hipMemcpyDeviceToHost));
+#ifdef PT_MEGA_STATS
+        fprintf(stderr, "mega stats: trips %llu, started per trip %.2f, finished per trip %.2f, maker iterations %llu (per trip %.3f) at %.1f lanes\n",
+                total2[2], (double)total2[3] / (double)(total2[2] ? total2[2] : 1), (double)total2[4] / (double)(total2[2] ? total2[2] : 1), total2[5],
+                (double)total2[5] / (double)(total2[2] ? total2[2] : 1), (double)total2[6] / (double)(total2[5] ? total2[5] : 1));
+        fprintf(stderr, "mega stats: lanes with an item %.2f, of them dry (no ray to start, samples used up) %.2f, lanes told no more %.2f per trip\n",
+                (double)total2[8] / (double)(total2[2] ? total2[2] : 1), (double)total2[9] / (double)(total2[2] ? total2[2] : 1),
+                (double)total2[10] / (double)(total2[2] ? total2[2] : 1));
+#endif
+        const unsigned long long total = total2[0];
+        if (total2[1]) {
+            set_error("megakernel: a lane's split stack overflowed");
+            return PT_ERR_OVERFLOW;
+        }
         stats->ray_bounces = total;
         stats->intersect_rays = 0;
         stats->intersect_launches = 0;

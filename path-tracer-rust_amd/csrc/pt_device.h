@@ -1265,6 +1265,7 @@ __device__ __forceinline__ void bvh_closest_queue4(const DevScene &S, NodePtr4 n
 #define PT_WALK_FORM 2
 #endif
 
+
 // LDS carve-up of the kernels that intersect: [BvhNode x n_bvh_nodes][u16 stack: kBvhStack x blockDim] when the
 // nodes are staged, else [u32 stack: kBvhStack x blockDim] alone (nodes read from global memory)
 __device__ __forceinline__ void stage_bvh(const DevScene &S, uint4 *lds) {
@@ -1678,6 +1679,8 @@ __device__ __forceinline__ void cand_filter_and_drain(const DevScene &S, const C
     // rays that graze the planes of an axis (|d_a| < kGrazing, or NaN): not judged by the filters of that axis
     const uint64_t gz_x = __builtin_amdgcn_ballot_w64(!(f_abs(d.x) >= kGrazing)), gz_y = __builtin_amdgcn_ballot_w64(!(f_abs(d.y) >= kGrazing)),
                    gz_z = __builtin_amdgcn_ballot_w64(!(f_abs(d.z) >= kGrazing));
+    // (Issuing the next record's scalar load before this record's arithmetic - a second sixteen-register tuple - was measured in
+    // round 4: 44.3 against 47.2 G bounces/s; the kernel is short of scalar registers, not of time to wait for them.)
     for (uint32_t p = 0; p < S.n_flat_exact; ++p) {  // the records with the exact sign rule (the host puts them first)
         const FlatPairRec f = ld_uniform(S.flat_pairs + p);
         uint64_t m0, m1;

@@ -41,8 +41,12 @@ void launch_scatter_chunks(hipStream_t st, const float *src, float *dst, uint32_
 void launch_resolve(hipStream_t st, const unsigned long long *acc, float *out, uint32_t npix, uint32_t spp,
                     uint32_t n_streams, uint32_t m, bool clamp = true);
 // one round of the megakernel: samples [s_begin, s_end) of every pixel, n_split lanes of lane_spp samples per pixel
+// (total_rays: [0] the ray counter, [1] an overflow flag of k_mega_cand's split stacks, [7] its item counter, which the caller
+// zeroes before every launch; stack_mem: mega_stack_mem_bytes(grid) bytes for the split stacks when mega_uses_cand(S), else unused)
 void launch_mega(hipStream_t st, uint32_t grid, const DevScene &S, const FrameParams &F, unsigned long long *acc,
-                 uint32_t s_begin, uint32_t s_end, uint32_t lane_spp, uint32_t n_split, unsigned long long *total_rays);
+                 uint32_t s_begin, uint32_t s_end, uint32_t lane_spp, uint32_t n_split, unsigned long long *total_rays, char *stack_mem);
+bool mega_uses_cand(const DevScene &S);
+size_t mega_stack_mem_bytes(uint32_t grid);
 void launch_query(hipStream_t st, const DevScene &S, const float *o, const float *d, uint32_t n, float *t,
                   int32_t *object_id, int32_t *tri_id, float *x, float *nrm);
 // mode 0: intersect_bounds of one object; mode 1: get_orbit_point (see k_bounds)

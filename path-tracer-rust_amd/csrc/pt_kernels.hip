@@ -1281,54 +1281,15 @@ __global__ __launch_bounds__(kBlock) void k_scatter_chunks(const float *__restri
 // The refract split (mod.rs:775-786) pushes the transmitted ray on a two-entry stack in registers.
 // One launch = one ROUND: the samples [s_begin, s_end) of every pixel of the call; item = (pixel, part of the round):
 // part k of `n_split` walks the samples s_begin + k*lane_spp ... (< s_end).
-// CAND (scenes without BVH meshes whose candidate records fit LDS): the closest hit by the candidate scan of k_pass_cand
-// (pt_device.h: spheres exactly, conservative filters, exact tests of the (ray, record) candidates in dense batches of the
-// wave, keys) instead of every object and triangle per lane - with every candidate of a trip tested within the trip (the last
-// batch of a trip is partial: a lane's path cannot wait a trip for its hit the way a stream's chunk can).
-#ifndef PT_MEGA_CAND_WAVES
-#define PT_MEGA_CAND_WAVES 4
-#endif
-template <bool BVH, bool PROBE, bool CAND = false>
-__global__ __launch_bounds__(kBlock, CAND ? PT_MEGA_CAND_WAVES : 1) void k_mega(DevScene S, FrameParams F, unsigned long long *__restrict__ acc,
+// (Scenes whose candidate records fit LDS run k_mega_cand below instead: the candidate scan, two paths per lane.  This form -
+// every object and triangle per lane - remains for PT_CAND_SCAN=0 / PT_FLAG_NO_BVH and for scenes with too many records.)
+template <bool BVH, bool PROBE>
+__global__ __launch_bounds__(kBlock) void k_mega(DevScene S, FrameParams F, unsigned long long *__restrict__ acc,
                                                  uint32_t s_begin, uint32_t s_end, uint32_t lane_spp, uint32_t n_split,
                                                  unsigned long long *__restrict__ total_rays) {
     const uint64_t items = (uint64_t)F.npix * n_split;
     unsigned long long rays = 0;
-    if (BVH && !CAND) stage_bvh(S, dyn_lds);
-    CandLds cand{};
-    CandRing ring;
-    ring.head = 0u;
-    ring.count = 0u;
-    const uint32_t lane = threadIdx.x & 63u;
-    // CAND with BVH meshes: a lane whose ray may hit one (bvh_wants) walks it in the same trip - the wave's walking rays
-    // share one queue of box tests (bvh_closest_queue), a handful per trip.  LDS after the candidate areas and the staged
-    // records: [per wave: walk queue][per wave: u64 key x 64]
-    WalkQueue wq{};
-    unsigned long long *walk_keys = nullptr;
-    if (CAND && BVH) {
-        char *wl = reinterpret_cast<char *>(dyn_lds) + intersect_cand_lds_bytes() + (((size_t)S.n_cand_pairs * sizeof(CandPairRec) + 15) & ~(size_t)15);
-        char *qb = wl + (size_t)(threadIdx.x >> 6) * pass_cand_queue_bytes(S);
-        wq.redo = reinterpret_cast<uint32_t *>(qb);
-        wq.ent = reinterpret_cast<uint2 *>(qb + kWalkQueueHeader);
-        wq.cap = (uint32_t)((pass_cand_queue_bytes(S) - kWalkQueueHeader) / 8u);
-        if (S.walk_queue_cap >= 128u && S.walk_queue_cap < wq.cap) wq.cap = S.walk_queue_cap;
-        walk_keys = reinterpret_cast<unsigned long long *>(wl + pass_cand_queues_bytes(S) + (size_t)(threadIdx.x >> 6) * kCandWalkKeyBytes);
-    }
-    if (CAND) {
-        char *wbase = reinterpret_cast<char *>(dyn_lds) + (size_t)(threadIdx.x >> 6) * kCandWaveBytes;
-        cand.ray_a = reinterpret_cast<float4 *>(wbase);
-        cand.keys = reinterpret_cast<unsigned long long *>(wbase + 128u * 16u);
-        cand.ray_b = reinterpret_cast<float2 *>(wbase + 128u * 24u);
-        cand.queue = reinterpret_cast<uint16_t *>(wbase + 128u * 32u);
-        char *sbase = reinterpret_cast<char *>(dyn_lds) + intersect_cand_lds_bytes();
-        cand.staged = reinterpret_cast<const CandPairRec *>(sbase);
-        cand.surf = S.surf;
-        const uint4 *src = reinterpret_cast<const uint4 *>(S.cand_pairs);
-        uint4 *dst = reinterpret_cast<uint4 *>(sbase);
-        const uint32_t n_rows = S.n_cand_pairs * (uint32_t)(sizeof(CandPairRec) / 16u);
-        for (uint32_t k = threadIdx.x; k < n_rows; k += kBlock) dst[k] = src[k];
-        __syncthreads();
-    }
+    if (BVH) stage_bvh(S, dyn_lds);
     for (uint64_t first = (uint64_t)blockIdx.x * kBlock; first < items; first += (uint64_t)gridDim.x * kBlock) {
         const uint64_t item = first + threadIdx.x;
         const bool lane_valid = item < items;
@@ -1367,26 +1328,8 @@ __global__ __launch_bounds__(kBlock, CAND ? PT_MEGA_CAND_WAVES : 1) void k_mega(
             HitRec h;
             h.t = 0.0f;
             h.id = -1;
-            if (CAND) {  // every lane of the wave takes part; the lanes without a ray have no candidates
-                cand.ray_a[lane] = make_float4(cur.o.x, cur.o.y, cur.o.z, cur.d.x);
-                cand.ray_b[lane] = make_float2(cur.d.y, cur.d.z);
-                float bound;
-                const unsigned long long key0 = cand_spheres(S, cur.o, cur.d, &bound);
-                cand.keys[lane] = active ? key0 : kKeyMiss;
-                cand_filter_and_drain<true>(S, cand, ring, lane, 0u, active, cur.o, cur.d, bound);
-                if (ring.count != 0u) cand_batch<true>(S, cand, ring, lane, ring.count);
-                unsigned long long key = load_key(&cand.keys[lane]);
-                if (BVH) {
-                    const bool want = active && bvh_wants(S, cur.o, cur.d, __uint_as_float((uint32_t)(key >> 32)));
-                    if (__builtin_amdgcn_ballot_w64(want) != 0ull)  // wave-uniform
-                        key = walk_deferred_keys(S, walk_nodes(S), cur.o, cur.d, wq, key, walk_keys, want);
-                }
-                const uint32_t rank = (uint32_t)key;
-                h.t = __uint_as_float((uint32_t)(key >> 32));
-                h.id = rank != 0xffffffffu ? (int32_t)S.rank_id[rank] : -1;
-            }
             if (active) {
-                if (!CAND) h = intersect_scene_dev<BVH>(S, cur.o, cur.d, dyn_lds);
+                h = intersect_scene_dev<BVH>(S, cur.o, cur.d, dyn_lds);
                 ++rays;
                 if (h.id < 0) {
                     active = false;
@@ -1427,6 +1370,359 @@ __global__ __launch_bounds__(kBlock, CAND ? PT_MEGA_CAND_WAVES : 1) void k_mega(
         }
     }
     // one counter update per wave
+    for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
+    if ((threadIdx.x & 63u) == 0u && rays) atomicAdd(total_rays, rays);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The megakernel with the candidate scan, round 4: TWO PATHS PER LANE, one trip apart.
+// k_mega<.., CAND> (round 3) finished every ray in the trip that started it: whatever the wave's ring held at the end of a
+// trip was tested as a partial batch (two batches per trip, the second nearly empty), and a lane whose path ended made the
+// whole wave run render_pixel's ray maker for its handful of lanes in EVERY trip.  Here a lane walks its item's samples as
+// two interleaved paths: a trip STARTS the ray of one path (spheres, filters, candidates to the ring, full batches - the ray
+// and its key wait in the lane's LDS slot of that parity) and FINISHES the ray the other path started a trip earlier (what
+// the ring still held of it has been tested by this trip's batches, or is now), shades it, and the continuation is the ray
+// the next trip starts.  That is k_pass_cand's trip with the rays bound to their lanes: no ray ever goes to memory, radiance
+// is summed in the lane's registers, and only the transmitted child of a refract split (mod.rs:775-786: at most two per path
+// are waiting) is put aside - on a four-entry stack per lane in global memory, touched when a split happens.
+// mesh.json: a lane whose finished ray may hit a BVH mesh (bvh_wants) walks it in that trip, all lanes of the wave working
+// the walk queue (as round 3).
+// PRIMARY RAYS IN DENSE ROUNDS.  A path ends after 8.7 bounces on average, so in every trip some seven of the wave's 64
+// lanes need render_pixel's next primary ray - and the ray maker (Philox, two tent filters, two divisions, a normalisation:
+// 150 instructions) ran in every trip for those seven.  Each lane therefore keeps up to `n_spare_max` (2 or 4) primary rays of its own
+// pixel's next samples in LDS (the direction: 16 B each; the origin is the lens), made in ROUNDS in which every lane with
+// room takes part, started when some lane that needs a ray has none: one round in four to five trips at about half the
+// lanes instead of one in every trip at a ninth.  (pt_ctx_radiance's fixed probe ray needs no maker and no spares.)
+// (two per lane, four where the workgroup's LDS has room for them: 8 / 16 KB)
+__host__ __device__ constexpr size_t mega_spare_bytes(uint32_t depth) { return (size_t)depth * kBlock * sizeof(float4); }
+constexpr size_t kMegaOwnerBytes = kBlock * sizeof(uint32_t);  // the rounds' owner tables
+struct MegaStack {
+    float4 *a;  // [4][lanes] origin xyz, direction x
+    float4 *b;  // [4][lanes] throughput rgb, meta
+    float2 *c;  // [4][lanes] direction yz
+    uint32_t lanes;
+};
+constexpr uint32_t kMegaStackEntries = 4;
+// items a wave takes from the global counter at a time.  Small: what a wave holds of its share when the counter runs out is
+// work the other waves cannot take over (cornell.json 1024x768 @1024, items of 43 samples: 256 per atomic 34.9, 128: 37.2, 64:
+// 41.0, 32: 41.3, 16: 41.1 G bounces/s) - and 100 000 atomics per launch are nothing.
+constexpr uint32_t kMegaItemChunk = 32;
+__host__ __device__ inline size_t mega_stack_bytes(uint32_t lanes) { return (size_t)lanes * kMegaStackEntries * 40u; }
+
+template <bool BVH, bool PROBE>
+__global__ __launch_bounds__(kBlock, 4) void k_mega_cand(DevScene S, FrameParams F, unsigned long long *__restrict__ acc,
+                                                         uint32_t s_begin, uint32_t s_end, uint32_t lane_spp, uint32_t n_split,
+                                                         unsigned long long *__restrict__ total_rays, MegaStack stk, uint32_t spare_off,
+                                                         uint32_t n_spare_max, uint32_t surf_off) {
+    const uint64_t items = (uint64_t)F.npix * n_split;
+    unsigned long long rays = 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t gl = blockIdx.x * kBlock + threadIdx.x;  // this lane's column of the split stacks
+    CandLds cand{};
+    CandRing ring;
+    ring.head = 0u;
+    ring.count = 0u;
+    WalkQueue wq{};
+    unsigned long long *walk_keys = nullptr;
+    if (BVH) {
+        char *wl = reinterpret_cast<char *>(dyn_lds) + intersect_cand_lds_bytes() + (((size_t)S.n_cand_pairs * sizeof(CandPairRec) + 15) & ~(size_t)15);
+        char *qb = wl + (size_t)(threadIdx.x >> 6) * pass_cand_queue_bytes(S);
+        wq.redo = reinterpret_cast<uint32_t *>(qb);
+        wq.ent = reinterpret_cast<uint2 *>(qb + kWalkQueueHeader);
+        wq.cap = (uint32_t)((pass_cand_queue_bytes(S) - kWalkQueueHeader) / 8u);
+        if (S.walk_queue_cap >= 128u && S.walk_queue_cap < wq.cap) wq.cap = S.walk_queue_cap;
+        walk_keys = reinterpret_cast<unsigned long long *>(wl + pass_cand_queues_bytes(S) + (size_t)(threadIdx.x >> 6) * kCandWalkKeyBytes);
+    }
+    {
+        char *wbase = reinterpret_cast<char *>(dyn_lds) + (size_t)(threadIdx.x >> 6) * kCandWaveBytes;
+        cand.ray_a = reinterpret_cast<float4 *>(wbase);
+        cand.keys = reinterpret_cast<unsigned long long *>(wbase + 128u * 16u);
+        cand.ray_b = reinterpret_cast<float2 *>(wbase + 128u * 24u);
+        cand.queue = reinterpret_cast<uint16_t *>(wbase + 128u * 32u);
+        char *sbase = reinterpret_cast<char *>(dyn_lds) + intersect_cand_lds_bytes();
+        cand.staged = reinterpret_cast<const CandPairRec *>(sbase);
+        cand.surf = S.surf;
+        const uint4 *src = reinterpret_cast<const uint4 *>(S.cand_pairs);
+        uint4 *dst = reinterpret_cast<uint4 *>(sbase);
+        const uint32_t n_rows = S.n_cand_pairs * (uint32_t)(sizeof(CandPairRec) / 16u);
+        for (uint32_t k = threadIdx.x; k < n_rows; k += kBlock) dst[k] = src[k];
+        if (surf_off != 0u) {  // the shading records by rank too, when they fit (as k_pass_cand)
+            const uint4 *src2 = reinterpret_cast<const uint4 *>(S.surf);
+            uint4 *dst2 = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(dyn_lds) + surf_off);
+            const uint32_t n_rows2 = (S.n_objs + S.n_tris) * (uint32_t)(sizeof(SurfRec) / 16u);
+            for (uint32_t k = threadIdx.x; k < n_rows2; k += kBlock) dst2[k] = src2[k];
+            cand.surf = reinterpret_cast<const SurfRec *>(dst2);
+        }
+        __syncthreads();
+    }
+    ShadeParams P{};  // (the RNG key as two scalars of its own: see k_pass_cand)
+    {
+        uint32_t k_lo = F.seed_lo, k_hi = F.seed_hi;
+        asm volatile("" : "+s"(k_lo), "+s"(k_hi));
+        P.seed_lo = k_lo;
+        P.seed_hi = k_hi;
+    }
+    // [n_spare_max][kBlock] float4 at the end of the workgroup's LDS: the lanes' spare primary rays (entry k of lane t at
+    // k * kBlock + t)
+    float4 *const spare = reinterpret_cast<float4 *>(reinterpret_cast<char *>(dyn_lds) + spare_off);
+    // ... and behind them, per wave, [64] u32: which lane owns the w-th ray of a round of the ray maker
+    uint32_t *const owner_of = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(dyn_lds) + spare_off + mega_spare_bytes(n_spare_max)) + (threadIdx.x & ~63u);
+    // ITEMS ARE HANDED OUT, NOT DEALT.  An item is (pixel, part of the round's samples); a lane takes its next one when its
+    // item is exhausted - from its wave's share of a counter in global memory (kMegaItemChunk items per atomic; the lanes that
+    // ask in a trip are numbered by a prefix count).  Dealt in advance - item k of a lane = first + k * stride - the lanes of
+    // a wave finish far apart: a pixel on the glass sphere costs three to four times the rays of one on a wall, and a wave
+    // whose 64 neighbouring pixels straddle its silhouette ran a third of its trips for its slowest lanes alone.  (One atomic
+    // per asking wave and trip instead of per chunk: at 6 M items per launch the ONE counter word saturates - 63 M atomics/s -
+    // and the waves wait half their lifetime for it: 25 G bounces/s against 39.)  The host zeroes the counter before a launch.
+    unsigned long long *const item_ctr = total_rays + 7;
+    unsigned long long pool_next = 0ull;  // wave-uniform: the wave's share of the counter
+    uint32_t pool_left = 0u;
+    bool have_item = false, no_more = false;
+    uint32_t pl = 0u, gpix = 0u, s = 0u, s_stop = 0u, n_spare = 0u;
+    uint64_t ar = 0, ag = 0, ab = 0;
+    {
+        // the ray the next trip starts (this lane's path of that parity), and what the ray started a trip ago still needs
+        PathRay cur;
+        cur.o = cur.d = cur.thr = mk(0.0f, 0.0f, 0.0f);
+        cur.pix = gpix;
+        cur.meta = 0;
+        bool cur_active = false;
+        vec3 prev_thr = mk(0.0f, 0.0f, 0.0f);
+        uint32_t prev_meta = 0;
+        bool prev_valid = false;
+        uint32_t sp = 0;   // entries on this lane's split stack
+        uint32_t par = 0;  // the slots (LDS) of the ray started in this trip
+        uint32_t w_room = 0u;  // wave-uniform: spare rays taken since the last round of the ray maker
+        for (;;) {
+            // 0. an item whose samples are all traced (nothing in flight, nothing waiting): its radiance goes to the pixel, the
+            //    lane asks for its next item
+            const bool ask = !cur_active && !prev_valid && sp == 0u && n_spare == 0u && s >= s_stop && !no_more;
+            const uint64_t m_ask = __builtin_amdgcn_ballot_w64(ask);
+            if (m_ask != 0ull) {  // wave-uniform
+                if (pool_left == 0u) {  // the wave's share of the counter is used up: kMegaItemChunk more
+                    unsigned long long got = 0ull;
+                    const uint32_t src = (uint32_t)__builtin_ctzll(m_ask);
+                    if (lane == src) got = atomicAdd(item_ctr, (unsigned long long)kMegaItemChunk);
+                    pool_next = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(got >> 32), (int)src) << 32) |
+                                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)got, (int)src);
+                    pool_left = kMegaItemChunk;
+                }
+                const uint32_t n_ask = (uint32_t)__builtin_popcountll(m_ask);
+                const uint32_t give = n_ask < pool_left ? n_ask : pool_left;  // (the others ask again in the next trip)
+                const uint32_t rank = lane_prefix(m_ask);
+                if (ask && rank < give) {
+                    if (have_item) {
+                        if (ar) atomicAdd(&acc[pl], (unsigned long long)ar);
+                        if (ag) atomicAdd(&acc[(size_t)F.npix + pl], (unsigned long long)ag);
+                        if (ab) atomicAdd(&acc[2 * (size_t)F.npix + pl], (unsigned long long)ab);
+                        ar = ag = ab = 0;
+                        have_item = false;
+                    }
+                    const unsigned long long item = pool_next + rank;
+                    if (item < items) {
+                        pl = (uint32_t)(item % F.npix);
+                        const uint32_t part = (uint32_t)(item / F.npix);
+                        s = s_begin + part * lane_spp;
+                        const uint32_t s_lim = s + lane_spp;
+                        s_stop = s_lim < s_end ? s_lim : s_end;
+                        if (s > s_stop) s = s_stop;
+                        gpix = global_pixel(F, pl);
+                        have_item = true;
+                    } else {
+                        no_more = true;
+                    }
+                }
+                pool_next += give;
+                pool_left -= give;
+            }
+            // 1. a path without a ray takes the lane's most recent split child, or the item's next sample
+            if (!cur_active) {
+                if (sp != 0u) {
+                    --sp;
+                    const size_t at = (size_t)sp * stk.lanes + gl;
+                    const float4 a = stk.a[at], b = stk.b[at];
+                    const float2 c2 = stk.c[at];
+                    cur.o = mk(a.x, a.y, a.z);
+                    cur.d = mk(a.w, c2.x, c2.y);
+                    cur.thr = mk(b.x, b.y, b.z);
+                    cur.meta = __float_as_uint(b.w);
+                    cur_active = true;
+                } else if (PROBE && s < s_stop) {
+                    cur = primary_ray<true>(F, gpix, s);
+                    ++s;
+                    cur_active = true;
+                }
+            }
+            if (!PROBE) {
+                // A round of the ray maker when the wave's lanes have room for 64 rays between them (w_room counts the spares
+                // taken since the last round), or a lane that needs a primary ray has no spare one.  THE WAVE MAKES THE RAYS
+                // TOGETHER: lane L has room for d_L rays (0..4: its pixel's next samples); the d_L are numbered through by a
+                // prefix count, and worker w makes the w-th ray of the round - whichever lane's pixel and sample that is
+                // (owner, pixel and sample index by ds_bpermute) - and writes it into the OWNER's spare slots.  A round is then 64
+                // rays by 64 lanes whatever the single lanes' deficits are; made by their owners, rounds ran for the few lanes
+                // with room (a lane that has just taken a new item starves four times in a row): 0.7 per trip at ten lanes.
+                const bool starved = !cur_active && n_spare == 0u && s < s_stop;
+                if (__builtin_amdgcn_ballot_w64(starved) != 0ull || w_room >= 64u) {
+                    w_room = 0u;
+                    for (;;) {
+                        const uint32_t left = s_stop - s, free_slots = n_spare_max - n_spare;
+                        const uint32_t d = left < free_slots ? left : free_slots;  // 0..4
+                        const uint64_t b0 = __builtin_amdgcn_ballot_w64((d & 1u) != 0u), b1 = __builtin_amdgcn_ballot_w64((d & 2u) != 0u),
+                                       b2 = __builtin_amdgcn_ballot_w64((d & 4u) != 0u);
+                        const uint32_t total = (uint32_t)__builtin_popcountll(b0) + 2u * (uint32_t)__builtin_popcountll(b1) +
+                                               4u * (uint32_t)__builtin_popcountll(b2);
+                        if (total == 0u) break;
+                        const uint32_t before = lane_prefix(b0) + 2u * lane_prefix(b1) + 4u * lane_prefix(b2);  // rays of the lanes below
+                        const uint32_t served = before >= 64u ? 0u : (before + d > 64u ? 64u - before : d);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        for (uint32_t k = 0; k < 4u; ++k)
+                            if (k < served) owner_of[before + k] = lane;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        const uint32_t n_make = total < 64u ? total : 64u;
+                        const uint32_t owner = lane < n_make ? owner_of[lane] : lane;
+                        const int sel = (int)(owner << 2);
+                        const uint32_t o_before = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)before);
+                        const uint32_t o_pix = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)gpix);
+                        const uint32_t o_s = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)s);
+                        if (lane < n_make) {
+                            const uint32_t smp = o_s + (lane - o_before);
+                            const PathRay r = primary_ray<false>(F, o_pix, smp);
+                            spare[(smp & (n_spare_max - 1u)) * kBlock + ((threadIdx.x & ~63u) | owner)] = make_float4(r.d.x, r.d.y, r.d.z, 0.0f);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        s += served;
+                        n_spare += served;
+#ifdef PT_MEGA_STATS
+                        if (lane == 0u) {
+                            atomicAdd(total_rays + 5, 1ull);
+                            atomicAdd(total_rays + 6, (unsigned long long)n_make);
+                        }
+#endif
+                        if (total <= 64u + 31u) break;  // (what is left would be a round of fewer than half the lanes)
+                    }
+                }
+                w_room += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(!cur_active && n_spare != 0u));
+                if (!cur_active && n_spare != 0u) {  // (the lane's own LDS entries: written and read by this lane only)
+                    const uint32_t smp = s - n_spare;
+                    const float4 dd = spare[(smp & (n_spare_max - 1u)) * kBlock + threadIdx.x];
+                    --n_spare;
+                    cur.o = mk(F.lens_x, F.lens_y, F.lens_z);
+                    cur.pix = gpix;
+                    cur.d = mk(dd.x, dd.y, dd.z);
+                    cur.thr = mk(1.0f, 1.0f, 1.0f);
+                    cur.meta = pack_meta(smp, 0u, 1u);  // radiance(&ray, 0, ..), mod.rs:844
+                    cur_active = true;
+                }
+            }
+            const uint64_t m_cur = __builtin_amdgcn_ballot_w64(cur_active), m_prev = __builtin_amdgcn_ballot_w64(prev_valid);
+            if (m_cur == 0ull && m_prev == 0ull) break;  // every path of the wave's items has ended
+#ifdef PT_MEGA_STATS
+            {
+                const unsigned long long n_item = (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(have_item));
+                const unsigned long long n_dry = (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(have_item && !cur_active && s >= s_stop && n_spare == 0u));
+                const unsigned long long n_nomore = (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(no_more));
+                if (lane == 0u) {
+                    atomicAdd(total_rays + 8, n_item);
+                    atomicAdd(total_rays + 9, n_dry);
+                    atomicAdd(total_rays + 10, n_nomore);
+                }
+            }
+            if (lane == 0u) {
+                atomicAdd(total_rays + 2, 1ull);
+                atomicAdd(total_rays + 3, (unsigned long long)__builtin_popcountll(m_cur));
+                atomicAdd(total_rays + 4, (unsigned long long)__builtin_popcountll(m_prev));
+            }
+#endif
+            // 2. start this trip's rays (every lane takes part; the lanes without one have no candidates)
+            const uint32_t pend_entries = ring.count;  // entries of the rays to finish that are still queued (< 64)
+            bool ran_batch = false;
+            if (m_cur != 0ull) {
+                const uint32_t slot = (par << 6) | lane;
+                cand.ray_a[slot] = make_float4(cur.o.x, cur.o.y, cur.o.z, cur.d.x);
+                cand.ray_b[slot] = make_float2(cur.d.y, cur.d.z);
+                float bound;
+                const unsigned long long key0 = cand_spheres(S, cur.o, cur.d, &bound);
+                cand.keys[slot] = cur_active ? key0 : kKeyMiss;
+                const uint32_t before = ring.head;
+                cand_filter_and_drain<true>(S, cand, ring, lane, par, cur_active, cur.o, cur.d, bound);
+                ran_batch = ring.head != before;
+            }
+            // 3. finish the rays started a trip ago
+            PathRay next;
+            next.o = next.d = next.thr = mk(0.0f, 0.0f, 0.0f);
+            next.pix = gpix;
+            next.meta = 0;
+            bool next_active = false;
+            if (m_prev != 0ull) {
+                if (pend_entries != 0u && !ran_batch) cand_batch<true>(S, cand, ring, lane, ring.count);
+                const uint32_t slot = ((par ^ 1u) << 6) | lane;
+                unsigned long long key = kKeyMiss;
+                PathRay pr;
+                pr.o = pr.d = mk(0.0f, 0.0f, 0.0f);
+                if (prev_valid) {
+                    key = load_key(&cand.keys[slot]);
+                    const float4 ra = cand.ray_a[slot];
+                    const float2 rb = cand.ray_b[slot];
+                    pr.o = mk(ra.x, ra.y, ra.z);
+                    pr.d = mk(ra.w, rb.x, rb.y);
+                }
+                if (BVH) {
+                    const bool want = prev_valid && bvh_wants(S, pr.o, pr.d, __uint_as_float((uint32_t)(key >> 32)));
+                    if (__builtin_amdgcn_ballot_w64(want) != 0ull)  // wave-uniform
+                        key = walk_deferred_keys(S, walk_nodes(S), pr.o, pr.d, wq, key, walk_keys, want);
+                }
+                if (prev_valid) {
+                    ++rays;
+                    const uint32_t rank = (uint32_t)key;
+                    if (rank != 0xffffffffu) {
+                        pr.thr = prev_thr;
+                        pr.pix = gpix;
+                        pr.meta = prev_meta;
+                        const Surface sf = fetch_surface_rank(cand.surf, pr.o, pr.d, __uint_as_float((uint32_t)(key >> 32)), rank);
+                        ShadeOut so;
+                        shade_surface<kShadeAll>(P, pr, sf, so);
+                        if (so.emits) {
+                            ar += to_fixed(so.contrib.x);
+                            ag += to_fixed(so.contrib.y);
+                            ab += to_fixed(so.contrib.z);
+                        }
+                        if (so.n_rays >= 1) {
+                            next.o = so.x;
+                            next.d = so.d0;
+                            next.thr = so.thr0;
+                            next.meta = so.meta0;
+                            next_active = true;
+                        }
+                        if (so.n_rays == 2 && sp >= kMegaStackEntries) {
+                            atomicOr(total_rays + 1, 1ull);  // (cannot happen: two paths, at most two waiting children each)
+                        } else if (so.n_rays == 2) {  // the transmitted child waits on the lane's stack
+                            const size_t at = (size_t)sp * stk.lanes + gl;
+                            stk.a[at] = make_float4(so.x.x, so.x.y, so.x.z, so.d1.x);
+                            stk.b[at] = make_float4(so.thr1.x, so.thr1.y, so.thr1.z, __uint_as_float(so.meta1));
+                            stk.c[at] = make_float2(so.d1.y, so.d1.z);
+                            ++sp;
+                        }
+                    }
+                }
+            }
+            // 4. the ray started in this trip waits; the continuation of the finished one is what the next trip starts
+            prev_thr = cur.thr;
+            prev_meta = cur.meta;
+            prev_valid = cur_active;
+            cur = next;
+            cur_active = next_active;
+            par ^= 1u;
+        }
+    }
+    // (every lane's last item was flushed in step 0 of the trip after its last ray: the loop only ends when no lane holds an
+    // item with anything left - a lane with have_item set at the exit has an exhausted item whose flush is still due)
+    if (have_item) {
+        if (ar) atomicAdd(&acc[pl], (unsigned long long)ar);
+        if (ag) atomicAdd(&acc[(size_t)F.npix + pl], (unsigned long long)ag);
+        if (ab) atomicAdd(&acc[2 * (size_t)F.npix + pl], (unsigned long long)ab);
+    }
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
     if ((threadIdx.x & 63u) == 0u && rays) atomicAdd(total_rays, rays);
 }
@@ -1822,21 +2118,33 @@ void launch_resolve(hipStream_t st, const unsigned long long *acc, float *out, u
                        n_streams, m, clamp ? 1u : 0u);
 }
 void launch_mega(hipStream_t st, uint32_t grid, const DevScene &S, const FrameParams &F, unsigned long long *acc,
-                 uint32_t s_begin, uint32_t s_end, uint32_t lane_spp, uint32_t n_split, unsigned long long *total_rays) {
+                 uint32_t s_begin, uint32_t s_end, uint32_t lane_spp, uint32_t n_split, unsigned long long *total_rays, char *stack_mem) {
     const size_t rec = ((size_t)S.n_cand_pairs * sizeof(CandPairRec) + 15) & ~(size_t)15;
     DevScene S2 = S;
     S2.bvh_in_lds &= ~5u;  // (the candidate forms read the nodes from global memory, with full-size walk queues)
     const size_t walk = S.n_bvh_nodes != 0u ? pass_cand_queues_bytes(S2) + (size_t)(kBlock / 64u) * kCandWalkKeyBytes : 0u;
-    if (S.cand_scan && intersect_cand_lds_bytes() + rec + walk <= 40u * 1024u) {  // the candidate scan
-        const size_t lds_c = intersect_cand_lds_bytes() + rec + walk;
+    if (mega_uses_cand(S) && stack_mem) {  // the candidate scan, two paths per lane (k_mega_cand)
+        const size_t rec_surf = (size_t)(S.n_objs + S.n_tris) * sizeof(SurfRec);
+        const size_t base = intersect_cand_lds_bytes() + rec + walk;
+        const size_t budget = 40u * 1024u;  // four workgroups per CU
+        const uint32_t depth = base + mega_spare_bytes(4) + kMegaOwnerBytes <= budget ? 4u : 2u;
+        const uint32_t spare_off = (uint32_t)base;
+        const size_t after = base + mega_spare_bytes(depth) + kMegaOwnerBytes;
+        const uint32_t surf_off = after + rec_surf <= budget ? (uint32_t)after : 0u;
+        const size_t lds_c = after + (surf_off ? rec_surf : 0u);
+        MegaStack stk;
+        stk.lanes = grid * kBlock;
+        stk.a = reinterpret_cast<float4 *>(stack_mem);
+        stk.b = stk.a + (size_t)kMegaStackEntries * stk.lanes;
+        stk.c = reinterpret_cast<float2 *>(stk.b + (size_t)kMegaStackEntries * stk.lanes);
         if (S.n_bvh_nodes != 0u && F.probe)
-            hipLaunchKernelGGL((k_mega<true, true, true>), dim3(grid), dim3(kBlock), lds_c, st, S2, F, acc, s_begin, s_end, lane_spp, n_split, total_rays);
+            hipLaunchKernelGGL((k_mega_cand<true, true>), dim3(grid), dim3(kBlock), lds_c, st, S2, F, acc, s_begin, s_end, lane_spp, n_split, total_rays, stk, spare_off, depth, surf_off);
         else if (S.n_bvh_nodes != 0u)
-            hipLaunchKernelGGL((k_mega<true, false, true>), dim3(grid), dim3(kBlock), lds_c, st, S2, F, acc, s_begin, s_end, lane_spp, n_split, total_rays);
+            hipLaunchKernelGGL((k_mega_cand<true, false>), dim3(grid), dim3(kBlock), lds_c, st, S2, F, acc, s_begin, s_end, lane_spp, n_split, total_rays, stk, spare_off, depth, surf_off);
         else if (F.probe)
-            hipLaunchKernelGGL((k_mega<false, true, true>), dim3(grid), dim3(kBlock), lds_c, st, S2, F, acc, s_begin, s_end, lane_spp, n_split, total_rays);
+            hipLaunchKernelGGL((k_mega_cand<false, true>), dim3(grid), dim3(kBlock), lds_c, st, S2, F, acc, s_begin, s_end, lane_spp, n_split, total_rays, stk, spare_off, depth, surf_off);
         else
-            hipLaunchKernelGGL((k_mega<false, false, true>), dim3(grid), dim3(kBlock), lds_c, st, S2, F, acc, s_begin, s_end, lane_spp, n_split, total_rays);
+            hipLaunchKernelGGL((k_mega_cand<false, false>), dim3(grid), dim3(kBlock), lds_c, st, S2, F, acc, s_begin, s_end, lane_spp, n_split, total_rays, stk, spare_off, depth, surf_off);
         return;
     }
     const size_t lds = S.n_bvh_nodes != 0u ? bvh_lds_bytes(S, kBlock) : 0u;
@@ -1849,6 +2157,15 @@ void launch_mega(hipStream_t st, uint32_t grid, const DevScene &S, const FramePa
     else
         hipLaunchKernelGGL((k_mega<false, false>), dim3(grid), dim3(kBlock), lds, st, S, F, acc, s_begin, s_end, lane_spp, n_split, total_rays);
 }
+// does the megakernel run the candidate scan for this scene (and need the split stacks: mega_stack_bytes)?
+bool mega_uses_cand(const DevScene &S) {
+    const size_t rec = ((size_t)S.n_cand_pairs * sizeof(CandPairRec) + 15) & ~(size_t)15;
+    DevScene S2 = S;
+    S2.bvh_in_lds &= ~5u;
+    const size_t walk = S.n_bvh_nodes != 0u ? pass_cand_queues_bytes(S2) + (size_t)(kBlock / 64u) * kCandWalkKeyBytes : 0u;
+    return S.cand_scan && intersect_cand_lds_bytes() + rec + walk + mega_spare_bytes(2) + kMegaOwnerBytes <= 40u * 1024u;
+}
+size_t mega_stack_mem_bytes(uint32_t grid) { return mega_stack_bytes(grid * kBlock); }
 void launch_query(hipStream_t st, const DevScene &S, const float *o, const float *d, uint32_t n, float *t,
                   int32_t *object_id, int32_t *tri_id, float *x, float *nrm) {
     uint32_t grid = (n + kBlock - 1) / kBlock;

@@ -1677,6 +1677,48 @@ def test_small_wave_stacks_hold_primaries_back(gpu):
             assert np.array_equal(res[name][0], res["1024"][0]), (sid, name)
 
 
+def test_megakernel_items_and_rounds_do_not_change_the_image(gpu):
+    """k_mega_cand (round 4): two paths per lane one trip apart, primary rays made in dense rounds of the whole wave, items -
+    (pixel, part of a round's samples) - handed out from a counter 32 at a time, split children on a stack per lane in
+    global memory.  None of that may show: the frame is the wavefront backend's, bit for bit, with the same number of
+    intersect_scene evaluations - for the default item size, for items of a handful of samples (PT_MEGA_ITEMS=256: many
+    hand-outs, every lane starved of spare rays all the time) and for one item per lane (PT_MEGA_ITEMS=1), with the rounds
+    the library chooses and with explicit rounds of a few samples, on cornell.json (glass: splits on the lanes' stacks) and on
+    mesh.json (walks inside the trip)."""
+    L, _ = gpu
+    for sid, (w, h, spp) in (("cornell", (320, 240, 96)), ("mesh", (256, 192, 48))):
+        sc = ptlib.load_scene_py(ptlib.scene_path(sid))
+        res = {}
+        for name, env, backend, rpp in (("wavefront", {}, 0, 0), ("mega", {}, 1, 0), ("tiny items", {"PT_MEGA_ITEMS": "256"}, 1, 0),
+                                        ("one item", {"PT_MEGA_ITEMS": "1"}, 1, 0), ("short rounds", {}, 1, w * h * 5)):
+            old = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            try:
+                ctx = C.c_void_p()
+                assert L.pt_ctx_create(0, C.byref(ctx)) == 0  # the tuning variables are read here
+            finally:
+                for k, v in old.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+            assert L.pt_ctx_set_scene(ctx, C.byref(sc.cam), sc.objs, sc.n_objs, sc.tris, sc.n_tris) == 0, L.pt_last_error()
+            cfg = PtConfig(w, h, spp, backend, 13, 0, 0, rpp, 0)
+            d = C.c_void_p()
+            assert L.pt_device_malloc(0, w * h * 12, C.byref(d)) == 0
+            st = PtStats()
+            assert L.pt_ctx_render(ctx, C.byref(cfg), d, None, None, None, None, C.byref(st)) == 0, L.pt_last_error()
+            img = np.empty((w * h, 3), np.float32)
+            assert L.pt_device_download(0, _np_f(img), d, img.nbytes) == 0
+            L.pt_device_free(0, d)
+            L.pt_ctx_destroy(ctx)
+            res[name] = (img, st.ray_bounces, st.passes)
+        assert res["short rounds"][2] >= spp // 5
+        for name in ("mega", "tiny items", "one item", "short rounds"):
+            assert res[name][1] == res["wavefront"][1], (sid, name)
+            assert np.array_equal(res[name][0], res["wavefront"][0]), (sid, name)
+
+
 def test_memory_budget_changes_the_passes_not_the_image(gpu):
     """pt_ctx_set_memory_budget: 8 MiB is less than the wave stacks of the 64-sample pass of a 128x96 frame take (2048 streams x
     4 waves x 512 slots x 40 B = 168 MB), so the pass is halved down to one sample per pixel and pass (the smallest stacks, 128

@@ -20,7 +20,8 @@ sc = ptlib.load_scene_py(ptlib.scene_path(scene))
 ctx = C.c_void_p()
 assert L.pt_ctx_create(0, C.byref(ctx)) == 0
 assert L.pt_ctx_set_scene(ctx, C.byref(sc.cam), sc.objs, sc.n_objs, sc.tris, sc.n_tris) == 0
-cfg = PtConfig(W, H, spp, backend, 1, 0, 0, 0, 0, 0, 0, 0, 0)
+rpp = int(os.environ.get("PT_ONE_FRAME_RPP", "0"))  # explicit pt_config.rays_per_pass (0: the library's own, timed passes)
+cfg = PtConfig(W, H, spp, backend, 1, 0, 0, rpp, 0, 0, 0, 0, 0)
 d = C.c_void_p()
 assert L.pt_device_malloc(0, W * H * 12, C.byref(d)) == 0
 st = PtStats()

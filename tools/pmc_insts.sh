@@ -6,6 +6,8 @@ set -e
 TAG=$1; LIB=$2; SCENE=${3:-cornell}; SPP=${4:-128}; BACKEND=${5:-0}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 export PT_LIB=$(realpath $LIB)
+# the default pass / round size, given explicitly: no short timed first passes in a one-frame profile
+if [ "$BACKEND" = "1" ]; then export PT_ONE_FRAME_RPP=268435456; else export PT_ONE_FRAME_RPP=536870912; fi
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/pmci_${TAG}
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAIT_ANY --kernel-trace --output-format csv -d $R/gpurun_out/pmci_${TAG} -- python3 $R/tools/one_frame.py $SCENE $SPP 1 $BACKEND > $R/gpurun_out/pmci_${TAG}.log 2>&1
