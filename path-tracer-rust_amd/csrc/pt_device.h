@@ -256,7 +256,11 @@ struct DevScene {
 // together with the wave's whole lifetime in s_memtime and s_memrealtime ticks (100 MHz): the clock the chip held.
 enum : uint32_t {
     kPhOther = 0, kPhLoad, kPhSpheres, kPhFilter, kPhBatch, kPhFinish, kPhSurface, kPhRng, kPhDiffuse, kPhSpecular, kPhGlass,
-    kPhAppend, kPhDefer, kPhBarrier, kPhWants, kPhWalkGate, kPhWalkBox, kPhWalkLeaf, kPhPrimary, kPhEmit, kPhCount
+    kPhAppend, kPhDefer, kPhBarrier, kPhWants, kPhWalkGate, kPhWalkBox, kPhWalkLeaf, kPhPrimary, kPhEmit,
+    // round 4, the EXEC budget: the divergent blocks INSIDE the phases above, stamped on their own (lanes at entry = the lanes
+    // that take the branch): a candidate's push to the ring, the second ray of a refract split, the roulette's rescale, the
+    // fixed-point adds of a hit on an emitter
+    kPhPush, kPhAppend2, kPhRoulette, kPhEmitAdd, kPhCount
 };
 struct PhaseLds {
     unsigned long long state[4];              // per wave of the workgroup: current phase << 32 | last stamp
@@ -1651,13 +1655,16 @@ __device__ __forceinline__ void cand_filter_and_drain(const DevScene &S, const C
         const uint32_t base = R.head + R.count;
         const uint32_t me = lane | (par << 6);
         if (__builtin_amdgcn_inverse_ballot_w64(m0)) {
+            PT_PHASE(kPhPush);
             const uint32_t at = (base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))) & (kCandQueueCap - 1u);
             L.queue[at] = (uint16_t)(me | (q0 << 7));
         }
         if (__builtin_amdgcn_inverse_ballot_w64(m1)) {
+            PT_PHASE(kPhPush);
             const uint32_t at = (base + n0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u))) & (kCandQueueCap - 1u);
             L.queue[at] = (uint16_t)(me | (q1 << 7));
         }
+        PT_PHASE(kPhFilter);
         R.count += n0 + (uint32_t)__builtin_popcountll(m1);
     };
     auto drain = [&]() {
@@ -1951,11 +1958,13 @@ __device__ __forceinline__ void shade_surface(const Params &F, const PathRay &in
     vec3 color = sf.color;
     bool alive = true;
     if (new_depth > 5u) {
+        PT_PHASE(kPhRoulette);
         if (unit_f32(rnd.a) < sf.max_refl && new_depth < (uint32_t)kMaxDepth)
             color = color * sf.inv_max_refl;
         else
             alive = false;
     }
+    PT_PHASE(kPhRng);
     const vec3 thr = in.thr * color;
     int n_rays = alive ? 1 : 0;
     vec3 d0 = d, thr0 = thr, d1 = d, thr1 = thr;

@@ -795,9 +795,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
         if (so.n_rays >= 1)
             store_ray(qs, wbase + lane_prefix(m1), so.x, so.d0, so.thr0,
                       pack_word(word_pix(word), word_sample(word), meta_depth(so.meta0), meta_branch(so.meta0)));
-        if (so.n_rays == 2)
+        if (so.n_rays == 2) {
+            PT_PHASE(kPhAppend2);
             store_ray(qs, wbase + c1 + lane_prefix(m2), so.x, so.d1, so.thr1,
                       pack_word(word_pix(word), word_sample(word), meta_depth(so.meta1), meta_branch(so.meta1)));
+        }
     };
     // DEFER: glass hits of this wave wait in its parking area until kCandDeferFlush of them make a dense wave
     uint32_t n_defer = 0;  // wave-uniform
@@ -990,7 +992,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
                     PT_PHASE(kPhEmit);
                     // (Collecting the hits on emitters per wave and adding them 64 at a time - 16 B per entry, dense fixed-point
                     // conversions and LDS atomics - was measured once the glass deferral had left its LDS free: +0.45 %, not kept.)
-                    if (so.emits) add_radiance_lds(lds_acc, m, word_pix(prev_word), so.contrib);
+                    if (so.emits) {
+                        PT_PHASE(kPhEmitAdd);
+                        add_radiance_lds(lds_acc, m, word_pix(prev_word), so.contrib);
+                    }
                 }
             }
             append(so, prev_word);

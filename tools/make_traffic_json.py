@@ -51,7 +51,8 @@ KERNELS = [("k_pass_cand<true, false, true, false, true>", "k_pass_candILb1ELb0E
            ("k_pass_cand<true, false, false, false, false>", "k_pass_candILb1ELb0ELb0ELb0ELb0", "k_pass_cand"),
            ("k_pass_cand<true, true, false, false, false>", "k_pass_candILb1ELb1ELb0ELb0ELb0", "k_pass_cand"), ("k_pass_bvh", "k_pass_bvhILb0", None),
            ("k_pass<", "k_passILb1ELb0", None), ("k_intersect_cand", "k_intersect_candILb1", None),
-           ("k_intersect<", "k_intersectILb0", "k_intersect"), ("k_mega", "k_megaILb0ELb0", None)]
+           ("k_intersect<", "k_intersectILb0", "k_intersect"), ("k_mega_cand<false, false>", "k_mega_candILb0ELb0", "k_mega_cand"),
+           ("k_mega<", "k_megaILb0ELb0", "k_mega")]
 done = {}
 for kname, sym, label in KERNELS:
     sq = kernel(out["sq"], kname)

@@ -10,7 +10,7 @@ import os
 import sys
 
 
-def correct(path, shipped_rate):
+def correct(path, shipped_rate, pmc_lanes=None):
     """Add the stamp-corrected budget to a budget file: the shipped library renders the same frame at `shipped_rate` ray
     bounces per second, i.e. in fewer wave-cycles per bounce than the stamped build; the difference, divided by the number
     of stamps, is what one stamp costs a wave, and a phase's corrected cycles are its stamped cycles minus its entries
@@ -26,6 +26,16 @@ def correct(path, shipped_rate):
         tot += p["corrected_wave_cycles_per_bounce"]
     for p in res["phases"].values():
         p["corrected_share"] = p["corrected_wave_cycles_per_bounce"] / tot
+    # THE EXEC BUDGET: a phase's corrected share of the waves' lifetime, weighted with the lanes that were active when it was
+    # entered - the kernel is bound by VALU issue, so time is a proxy for instructions - is what the PMC pair
+    # SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU measures as "lanes active per VALU instruction" (a third argument names it)
+    lanes = sum(p["corrected_share"] * p["lanes_at_entry"] for p in res["phases"].values())
+    res["time_weighted_active_lanes"] = lanes
+    if pmc_lanes is not None:
+        res["pmc_active_lanes_per_valu_instruction"] = pmc_lanes
+    res["exec_budget"] = {n: {"share_of_time": p["corrected_share"], "lanes": p["lanes_at_entry"],
+                              "lane_slots_lost_share": p["corrected_share"] * (64.0 - p["lanes_at_entry"]) / 64.0}
+                          for n, p in sorted(res["phases"].items(), key=lambda kv: -kv[1]["corrected_share"] * (64.0 - kv[1]["lanes_at_entry"]))}
     res["shipped_bounces_per_s"] = shipped_rate
     res["shipped_wave_cycles_per_bounce"] = shipped_cyc
     res["stamp_cost_wave_cycles"] = per_stamp
@@ -34,11 +44,13 @@ def correct(path, shipped_rate):
     print("%s: shipped %.2f G bounces/s = %.0f wave-cycles per 64 bounces; a stamp costs %.0f; corrected sum %.0f" %
           (path, shipped_rate / 1e9, shipped_cyc, per_stamp, tot))
     for n, p in sorted(res["phases"].items(), key=lambda kv: -kv[1]["corrected_share"]):
-        print("  %-20s %5.1f %%  (stamped %5.1f %%)  %5.1f lanes" % (n, 100 * p["corrected_share"], 100 * p["share"], p["lanes_at_entry"]))
+        print("  %-22s %5.1f %%  (stamped %5.1f %%)  %5.1f lanes  -> %4.1f %% of the lane slots idle here" %
+              (n, 100 * p["corrected_share"], 100 * p["share"], p["lanes_at_entry"], 100 * p["corrected_share"] * (64.0 - p["lanes_at_entry"]) / 64.0))
+    print("  time-weighted active lanes %.1f of 64%s" % (lanes, "" if pmc_lanes is None else "  (PMC, per VALU instruction: %.1f)" % pmc_lanes))
 
 
 if len(sys.argv) > 1 and sys.argv[1] == "--correct":
-    correct(sys.argv[2], float(sys.argv[3]))
+    correct(sys.argv[2], float(sys.argv[3]), float(sys.argv[4]) if len(sys.argv) > 4 else None)
     sys.exit(0)
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
@@ -47,7 +59,7 @@ from ptlib import PtConfig, PtStats
 
 NAMES = ["other", "load_ray", "spheres", "filter_push", "exact_batch", "finish_bookkeeping", "surface_fetch", "rng_roulette",
          "diffuse", "specular", "glass", "append", "glass_defer", "barrier", "bvh_wants", "walk_gate", "walk_box_batch",
-         "walk_leaf_batch", "primary_ray", "emit"]
+         "walk_leaf_batch", "primary_ray", "emit", "push_to_ring", "append_second_ray", "roulette_rescale", "emit_fixed_point_adds"]
 
 ptlib.PRODUCT_SO = os.environ["PT_LIB"]
 L = ptlib.product()
@@ -59,7 +71,7 @@ sc = ptlib.load_scene_py(ptlib.scene_path(scene))
 ctx = C.c_void_p()
 assert L.pt_ctx_create(0, C.byref(ctx)) == 0
 assert L.pt_ctx_set_scene(ctx, C.byref(sc.cam), sc.objs, sc.n_objs, sc.tris, sc.n_tris) == 0
-cfg = PtConfig(W, H, spp, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0)
+cfg = PtConfig(W, H, spp, 0, 1, 0, 0, 512 << 20, 0, 0, 0, 0, 0)  # (the default pass size, given explicitly: no timed short passes)
 d = C.c_void_p()
 assert L.pt_device_malloc(0, W * H * 12, C.byref(d)) == 0
 L.pt_debug_phase_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_uint32]

@@ -6,7 +6,9 @@ TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 # (--rays-per-pass: the default pass size given explicitly, so that the one profiled frame has no short timed first pass)
-ARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-variants --rays-per-pass 536870912 $@"
+# (PMC_NO_RPP=1: not for the level-by-level forms, whose queues hold 352 B per primary ray of a pass)
+RPP="--rays-per-pass 536870912"; if [ -n "$PMC_NO_RPP" ]; then RPP=""; fi
+ARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-variants $RPP $@"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${TAG}_sq -- python3 $R/bench.py $ARGS > $R/gpurun_out/pmc_${TAG}_sq.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${TAG}_fetch -- python3 $R/bench.py $ARGS > $R/gpurun_out/pmc_${TAG}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${TAG}_write -- python3 $R/bench.py $ARGS > $R/gpurun_out/pmc_${TAG}_write.log 2>&1
