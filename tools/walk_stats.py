@@ -18,7 +18,7 @@ sc = ptlib.load_scene_py(ptlib.scene_path(scene))
 ctx = C.c_void_p()
 assert L.pt_ctx_create(0, C.byref(ctx)) == 0
 assert L.pt_ctx_set_scene(ctx, C.byref(sc.cam), sc.objs, sc.n_objs, sc.tris, sc.n_tris) == 0
-cfg = PtConfig(W, H, spp, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0)
+cfg = PtConfig(W, H, spp, 0, 1, 0, 0, 512 << 20, 0, 0, 0, 0, 0)  # (the default pass size, given explicitly: no short timed passes, whose sessions are nearly empty)
 d = C.c_void_p()
 assert L.pt_device_malloc(0, W * H * 12, C.byref(d)) == 0
 st = PtStats()
