@@ -113,3 +113,31 @@ def test_bench_collective_at_world_size_1(gather):
     assert b["gather_ms"] is not None and 0 <= b["gather_ms"] < 1e3 and abs(b["gather_ms"] - pr["gather_ms"]["mean"]) < 1e-6
     assert len(b["config"]["kernel_isa_hash"]) == 16 and b["config"]["build_flags_complete"] is True
     assert isinstance(b["roofline"]["profile_matches_binary"], bool) and "hbm_counter_frac" in b["roofline"] and b["roofline"]["l2_frac"] > 0
+
+
+def test_bench_two_rank_rehearsal_reports_per_rank_times():
+    """bench.py with TWO ranks on this box's one GPU (PT_BENCH_DIST_BACKEND=gloo: the ranks share the device and the rows travel
+    through host memory - a rehearsal of the N > 1 code path, not a measurement): interleaved rows, the all-gather, the
+    reassembled frame - the single rank's image hash and bounce count - and the per-rank diagnosis line (render / gather
+    milliseconds and bounces as min / max / mean over the ranks, gathered once after the timed region)."""
+    import json
+    import subprocess
+    import sys
+
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--spp", "16", "--width", "128",
+            "--height", "96", "--no-variants", "--no-cpu-baseline"]
+    one = subprocess.run(base, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-3000:]
+    env = dict(os.environ, PT_BENCH_DIST_BACKEND="gloo")
+    two = subprocess.run(base + ["--gpus", "2"], capture_output=True, text=True, timeout=600, env=env)
+    assert two.returncode == 0, (two.stdout + two.stderr)[-3000:]
+    a = json.loads(one.stdout.strip().splitlines()[-1])
+    b = json.loads([l for l in two.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert b["n_gpus"] == 2 and b["scaling"] == "strong" and "rehearsal" in b["config"]["collective"]
+    assert b["config"]["image_hash"] == a["config"]["image_hash"]
+    assert b["config"]["ray_bounces_per_frame"] == a["config"]["ray_bounces_per_frame"]
+    pr = b["per_rank"]
+    for k in ("render_ms", "gather_ms", "ray_bounces"):
+        assert pr[k]["min"] <= pr[k]["mean"] <= pr[k]["max"], (k, pr[k])
+    assert abs(2 * pr["ray_bounces"]["mean"] - b["config"]["ray_bounces_per_frame"]) < 1.0  # the ranks' rows make up the frame
+    assert pr["render_ms"]["min"] > 0 and b["gather_ms"] is not None
