@@ -48,7 +48,7 @@ extern "C" {
 
 /* backends of the hot path (both run on the GPU) */
 #define PT_BACKEND_WAVEFRONT 0u /* SoA ray queues in HBM, generate/intersect/shade kernels per bounce */
-#define PT_BACKEND_MEGAKERNEL 1u /* persistent threads: whole render_pixel loop per lane */
+#define PT_BACKEND_MEGAKERNEL 1u /* persistent threads: whole render_pixel loop per lane (two interleaved paths), no ray queues */
 
 /* pt_config.flags */
 #define PT_FLAG_NO_BVH 1u /* meshes are scanned triangle by triangle as the reference does (mod.rs:558) */
@@ -105,8 +105,9 @@ typedef struct pt_config {
     uint64_t seed;     /* key of the counter-based RNG that stands in for rand::random (mod.rs:53) */
     uint32_t idx_begin; /* framebuffer-index band [idx_begin, idx_end) to render; 0,0 = whole frame */
     uint32_t idx_end;
-    uint32_t rays_per_pass; /* wavefront: primary rays generated per pass; 0 = library default (512 Mi: about 0.1 s per
-                             * pass on the bench scene - cancel and progress are looked at between passes) */
+    uint32_t rays_per_pass; /* wavefront: primary rays per pass (megakernel: primary samples per round); 0 = the library's own:
+                             * passes sized by measured time, at most 512 Mi primary rays - cancel and progress are looked
+                             * at between passes */
     uint32_t flags;
     /* Interleaved partition of the band for load balance across ranks (the cost of a pixel varies over the
      * image: contiguous eighths of cornell.json differ by up to 1.31x).  The band is cut into chunks of
@@ -174,9 +175,12 @@ uint32_t pt_config_pixels(const pt_config *cfg);
  * pt_config_pixels(cfg)*3 floats, pixel k of the call at element k*3+c, linear, clamped to [0,1] — for an
  * un-chunked band the memory image of the reference's Vec<Vec3> slice (mod.rs:1013-1014, 852-856).
  * `hip_stream` is a hipStream_t (NULL = the context's own stream).  Blocking.
- * Cancel (both backends): *cancel is read between passes (wavefront: one pass = one launch of a few ms; megakernel: one
- * round of about 0.1 s).  On PT_CANCELLED the buffer holds every pixel averaged over the samples that were accumulated
- * (stats->samples / pixels of the call), all zero if none - the picture pt_ctx_snapshot would have given. */
+ * Cancel (both backends): *cancel is read between passes (wavefront) / rounds (megakernel), which the library sizes by MEASURED
+ * time when rays_per_pass is 0 - a tiny timed first pass of a scene, then as many samples as fit 100-120 ms, the rate kept with
+ * the context - so a cancel comes back within about a tenth of a second whatever a ray of the scene costs (the reference polls
+ * its flag every 100 ms, mod.rs:947-958); with an explicit rays_per_pass a pass is as long as asked for.  On PT_CANCELLED the
+ * buffer holds every pixel averaged over the samples that were accumulated (stats->samples / pixels of the call), all zero if
+ * none - the picture pt_ctx_snapshot would have given. */
 int pt_ctx_render(pt_ctx *ctx, const pt_config *cfg, void *d_out_rgb, void *hip_stream,
                   const volatile uint8_t *cancel, pt_progress_fn cb, void *user, pt_stats *stats);
 
