@@ -489,17 +489,7 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
         }
         const uint32_t s0 = s_next;
         uint32_t s_here = (cfg->spp - s0) < spp_pass ? (cfg->spp - s0) : spp_pass;
-        if (adaptive) {
-            uint64_t fit = rate > 0.0 ? (uint64_t)(rate * kPassTargetMs / (double)npix) : kProbeRays / npix;
-            if (s_prev && fit > 16ull * s_prev) fit = 16ull * s_prev;
-            if (fit < 1u) fit = 1u;
-            if (fit > spp_pass) fit = spp_pass;
-            // the rest of the frame in equal passes, each up to a fifth longer than the target rather than one pass more
-            uint64_t stretch = fit + fit / 5u;
-            if (stretch > spp_pass) stretch = spp_pass;
-            const uint32_t left = cfg->spp - s0, n_left = (uint32_t)((left + stretch - 1u) / stretch);
-            s_here = (left + n_left - 1u) / n_left;
-        }
+        if (adaptive) s_here = host::next_pass_samples(rate, kPassTargetMs, npix, kProbeRays, s_prev, cfg->spp - s0, spp_pass);
         s_next = s0 + s_here;
         s_prev = s_here;
         c->live_spp_issued = s0 + s_here;
@@ -672,14 +662,7 @@ int render_mega(pt_ctx *c, const pt_config *cfg, const FrameParams &F, hipStream
         const uint32_t s0 = s_next;
         uint32_t s_here = (cfg->spp - s0) < round_spp ? (cfg->spp - s0) : round_spp;
         if (adaptive) {
-            uint64_t fit = rate > 0.0 ? (uint64_t)(rate * kRoundTargetMs / (double)npix) : kProbeSamples / npix;
-            if (s_prev && fit > 16ull * s_prev) fit = 16ull * s_prev;
-            if (fit < 1u) fit = 1u;
-            if (fit > round_spp) fit = round_spp;
-            uint64_t stretch = fit + fit / 5u;
-            if (stretch > round_spp) stretch = round_spp;
-            const uint32_t left = cfg->spp - s0, n_left = (uint32_t)((left + stretch - 1u) / stretch);
-            s_here = (left + n_left - 1u) / n_left;
+            s_here = host::next_pass_samples(rate, kRoundTargetMs, npix, kProbeSamples, s_prev, cfg->spp - s0, round_spp);
             HIP_TRY(hipEventRecord(round_begin[r & 1], st));
         }
         s_next = s0 + s_here;

@@ -799,5 +799,18 @@ int plan_pass(const PassPlanIn &in, PassPlan &out, uint64_t *want_next) {
     return kPlanOk;
 }
 
+uint32_t next_pass_samples(double rate, double target_ms, uint64_t npix, uint64_t probe, uint32_t s_prev, uint32_t left,
+                           uint32_t max_pass) {
+    if (npix == 0u) npix = 1u;
+    uint64_t fit = rate > 0.0 ? (uint64_t)(rate * target_ms / (double)npix) : probe / npix;
+    if (s_prev && fit > 16ull * s_prev) fit = 16ull * s_prev;
+    if (fit < 1u) fit = 1u;
+    if (fit > max_pass) fit = max_pass;
+    uint64_t stretch = fit + fit / 5u;
+    if (stretch > max_pass) stretch = max_pass;
+    const uint32_t n_left = (uint32_t)((left + stretch - 1u) / stretch);
+    return (left + n_left - 1u) / n_left;
+}
+
 }  // namespace host
 }  // namespace pt

@@ -75,6 +75,14 @@ struct PassPlan {
 enum { kPlanOk = 0, kPlanRetry = 1, kPlanTooLarge = 2 };
 // kPlanRetry: the plan does not fit (the stacks' budget, or 32-bit slot indices) - try again with in.want = *want_next
 int plan_pass(const PassPlanIn &in, PassPlan &out, uint64_t *want_next);
+// Samples of a pixel in the next pass (wavefront) / round (megakernel) of a frame whose passes follow the scene (pt_api.hip:
+// render_wavefront, render_mega).  `rate`: primary samples per millisecond the last timed pass went through (0: nothing
+// measured yet - the pass is `probe` samples in all); `s_prev`: samples per pixel of the pass before (0: none); `left`: samples
+// per pixel still to be issued (> 0); `max_pass`: what one pass may hold.  As many samples as `rate` fits into `target_ms`, at
+// most sixteen times the pass before, the rest of the frame in equal passes - each up to a fifth longer than the target
+// rather than one pass more.
+uint32_t next_pass_samples(double rate, double target_ms, uint64_t npix, uint64_t probe, uint32_t s_prev, uint32_t left,
+                           uint32_t max_pass);
 bool flatten_scene(const pt_camera &cam, const pt_object *objs, uint32_t n_objs, const pt_triangle *tris,
                    uint32_t n_tris, FlatScene &out, std::string &err);
 

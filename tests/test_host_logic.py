@@ -384,3 +384,46 @@ def test_pass_plan(tmp_path):
     assert plan(1 << 20, 32767, 1 << 31, default=0, stack=0) == "TOOLARGE"
     spp_pass, m, K, cap, retries = plan(1 << 20, 32767, 1 << 31, default=1, stack=0)  # the same as a default: halved until it fits
     assert retries >= 1 and K * cap <= 0x7fffffff
+
+
+PASS_SRC = r"""
+#include <cstdio>
+#include <cstdint>
+#include "pt_host.h"
+using namespace pt;
+int main() {
+    const uint64_t npix = 1024u * 768u, probe = 1u << 20;
+    // nothing measured yet: the probe (1 Mi primary rays = one sample per pixel of this frame)
+    if (host::next_pass_samples(0.0, 100.0, npix, probe, 0, 4096, 683) != 1) { printf("FAIL probe\n"); return 1; }
+    // a tiny frame's probe is never less than one sample
+    if (host::next_pass_samples(0.0, 100.0, 4096u * 4096u, probe, 0, 100, 32) != 1) { printf("FAIL probe floor\n"); return 1; }
+    // a measured rate is followed, but a pass grows at most sixteen-fold (short passes measure overheads), plus the fifth by which a
+    // pass may be stretched: 19 after 1, 292 after 16
+    const double rate = 5.5e6;  // primary samples per ms: cornell.json on an MI355X
+    if (host::next_pass_samples(rate, 100.0, npix, probe, 1, 4095, 683) != 19) { printf("FAIL growth\n"); return 1; }
+    if (host::next_pass_samples(rate, 100.0, npix, probe, 16, 4079, 683) != 292) { printf("FAIL growth 2 %u\n", host::next_pass_samples(rate, 100.0, npix, probe, 16, 4079, 683)); return 1; }
+    // steady state: 699 samples would fit 100 ms, the plan allows 683: the bench frame is six equal passes of 683
+    if (host::next_pass_samples(rate, 100.0, npix, probe, 683, 4096, 683) != 683) { printf("FAIL steady\n"); return 1; }
+    // equal passes over what is left, each at most a fifth longer than the target rather than one pass more:
+    // mesh.json's rate fits 448 samples into 100 ms; 1024 left -> two passes of 512 (114 ms), not three of 342
+    if (host::next_pass_samples(3.52e6, 100.0, npix, probe, 512, 1024, 683) != 512) { printf("FAIL stretch\n"); return 1; }
+    if (host::next_pass_samples(3.52e6, 100.0, npix, probe, 512, 1100, 683) != 367) { printf("FAIL equal %u\n", host::next_pass_samples(3.52e6, 100.0, npix, probe, 512, 1100, 683)); return 1; }
+    // a scene fifty times dearer: passes of a tenth of a second are a handful of samples; never zero, never beyond what is left
+    if (host::next_pass_samples(rate / 50.0, 100.0, npix, probe, 8, 10000, 683) != 15) { printf("FAIL dear %u\n", host::next_pass_samples(rate / 50.0, 100.0, npix, probe, 8, 10000, 683)); return 1; }
+    if (host::next_pass_samples(1.0, 100.0, npix, probe, 1, 3, 683) != 1) { printf("FAIL floor\n"); return 1; }
+    if (host::next_pass_samples(rate, 100.0, npix, probe, 683, 5, 683) != 5) { printf("FAIL left\n"); return 1; }
+    printf("OK\n");
+    return 0;
+}
+"""
+
+
+def test_pass_length_follows_the_measured_rate(tmp_path):
+    """host::next_pass_samples (render_wavefront / render_mega): the probe, the sixteen-fold growth limit, the plan's cap, equal
+    passes stretched by at most a fifth, floors - the arithmetic behind "a cancel comes back within a tenth of a second"."""
+    src = tmp_path / "p.cpp"
+    src.write_text(PASS_SRC)
+    exe = str(tmp_path / "p")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ptlib.PKG, "csrc"), "-I", os.path.join(ptlib.ROOT, "include"),
+                           str(src), "-o", exe, "-L", ptlib.PKG, "-lptrace_hip", "-Wl,-rpath," + ptlib.PKG])
+    assert subprocess.check_output([exe]).decode().strip() == "OK"
