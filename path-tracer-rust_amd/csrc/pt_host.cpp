@@ -706,7 +706,11 @@ int plan_pass(const PassPlanIn &in, PassPlan &out, uint64_t *want_next) {
     // longer streams - 2 048 of 384 pixels, two rounds of resident workgroups - lose: 42.0 against 46.4; 4 096: 43.4; 8 192:
     // 45.1 - same instruction count, but a fifth of the launch with few workgroups left (PMC: busy cycles per bounce 1.97
     // against 1.64 at fewer wave-cycles): streams are not equally long and two rounds cannot average that out)
-    const uint64_t per_stream = in.stack_form ? (uint64_t)(in.per_stream ? in.per_stream : 24576u) : (in.has_bvh ? 4096u : 2048u);
+    // (round 4, with the walk queue over the four-wide tree: scenes with walks a little shorter - mesh.json 1024x768 @1024,
+    // 18 Ki primaries per stream 29.0, 20 Ki 29.1, 21-22 Ki 29.2, 24 Ki 28.7, 32 Ki 28.5 G bounces/s; cornell.json is flat from 12 Ki to
+    // 48 Ki: 47.2-47.7)
+    const uint64_t per_stream = in.stack_form ? (uint64_t)(in.per_stream ? in.per_stream : (in.has_bvh ? 22528u : 24576u))
+                                              : (in.has_bvh ? 4096u : 2048u);
     uint64_t k_target = (npix * spp_pass + per_stream - 1u) / per_stream;
     if (k_target < 2048u) k_target = 2048u;
     if (in.streams) k_target = in.streams;

@@ -369,8 +369,8 @@ def test_pass_plan(tmp_path):
     spp_pass, m, K, cap, _ = plan(npix, 4096, 512 << 20)
     assert spp_pass == 683 and cap == 4096 and -(-4096 // spp_pass) == 6 and 4096 - 5 * spp_pass > 600  # six equal passes
     assert (m, K) == (32, 24576)  # streams of about 24 Ki primaries (36 pixels), nudged to whole rounds of 1024 resident workgroups
-    spp_pass, m, K, cap, _ = plan(npix, 1024, 512 << 20, park=1, bvh=1)  # mesh.json: two passes of 512, no nudge
-    assert spp_pass == 512 and m == -(-npix // -(-npix * 512 // 24576)) and cap == 4096
+    spp_pass, m, K, cap, _ = plan(npix, 1024, 512 << 20, park=1, bvh=1)  # mesh.json: two passes of 512, streams of 22 Ki primaries for scenes with walks, no nudge
+    assert spp_pass == 512 and m == -(-npix // -(-npix * 512 // 22528)) and cap == 4096
     spp_pass, m, K, cap, _ = plan(npix, 128, 512 << 20)  # few samples: one pass, short streams of at most 64 (+ nudge) pixels
     assert spp_pass == 128 and m <= 72 and K >= 10922
     spp_pass, m, K, cap, retries = plan(128 * 96, 64, 512 << 20, budget=8 << 20)  # the budget test of the GPU suite
