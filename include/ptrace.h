@@ -146,8 +146,9 @@ typedef void (*pt_progress_fn)(void *user, float fraction);
 typedef struct pt_ctx pt_ctx;
 
 const char *pt_version(void);
-/* the back-end (-mllvm) switches the library was built with: the Makefile probes each against the compiler and drops the
- * ones it rejects (they only steer instruction placement: same images with any subset) */
+/* the back-end (-mllvm) switches the library was built with, "<general set> | flat: <set of the pass kernel without walks>": the
+ * Makefile probes each against the compiler and drops the ones it rejects (they only steer instruction placement: same images
+ * with any subset) */
 const char *pt_build_flags(void);
 /* the first 16 hex digits of sha256 over the device assembly the library's kernels were built from (Makefile: pt_kernels.s of
  * the same compile): the _traffic.json files under profiles/ name the hash of the library they were measured on, bench.py compares */

@@ -372,6 +372,7 @@ int render_wavefront(pt_ctx *c, const pt_config *cfg, const FrameParams &frame, 
         pin.per_stream = c->tune.per_stream;
         pin.wave_stack = c->tune.wave_stack;
         pin.n_cus = c->n_cus;
+        pin.groups_per_cu = !stack_form ? 4u : (c->scene.n_bvh_nodes == 0u ? (uint32_t)PT_CAND_WAVES : (uint32_t)PT_CAND_BVH_WAVES);
         pin.stack_budget = stack_budget;
         host::PassPlan plan;
         uint64_t want_next = want;

@@ -736,7 +736,7 @@ int plan_pass(const PassPlanIn &in, PassPlan &out, uint64_t *want_next) {
     // shorter ones otherwise.
     bool small_frame = false;
     if (in.stack_form && !in.streams && in.n_cus != 0u && m >= 4u) {
-        const uint64_t resident = (uint64_t)in.n_cus * 4u;
+        const uint64_t resident = (uint64_t)in.n_cus * (in.groups_per_cu ? in.groups_per_cu : 4u);
         const uint64_t k_tuned = (npix + m - 1u) / m;
         if ((k_tuned + resident - 1u) / resident < 16u) {
             small_frame = true;
@@ -754,7 +754,7 @@ int plan_pass(const PassPlanIn &in, PassPlan &out, uint64_t *want_next) {
         }
     }
     if (!small_frame && in.cand_scan && !in.has_bvh && !in.streams && in.n_cus != 0u && m >= 8u) {
-        const uint64_t resident = (uint64_t)in.n_cus * 4u;
+        const uint64_t resident = (uint64_t)in.n_cus * (in.groups_per_cu ? in.groups_per_cu : 4u);
         uint32_t best_m = m;
         uint64_t best_cost = ~0ull;
         for (uint32_t mm = m - m * 15u / 100u; mm <= m + m / 5u && mm <= (in.stack_form ? 72u : kMaxStreamPixels); ++mm) {
@@ -774,7 +774,10 @@ int plan_pass(const PassPlanIn &in, PassPlan &out, uint64_t *want_next) {
     // k_pass_cand keeps a wave's waiting rays on a stack of at most kWaveStackMax slots (a quarter of the stream's slice
     // per wave, a power of two of at least 128 slots; a pass whose waves' whole quarters fit a smaller stack gets that)
     if (in.stack_form) {
-        const uint64_t need_w = (uint64_t)m * spp_pass + 8u;
+        // (a wave gets every fourth chunk of 64 of the stream's m * spp_pass primaries: at most ceil(chunks / 4) * 64 of them, each
+        // with at most four descendants waiting at a time - k_pass_cand's `room_for_all`)
+        const uint64_t n_prim = (uint64_t)m * spp_pass, most = ((n_prim + 63u) / 64u + 3u) / 4u * 64u;
+        const uint64_t need_w = 4u * (most < n_prim ? most : n_prim) + 3u;
         uint64_t cap_w = 128u;
         const uint64_t stack_max = in.wave_stack ? in.wave_stack : kWaveStackMax;
         while (cap_w < need_w && cap_w < stack_max) cap_w *= 2u;

@@ -63,6 +63,7 @@ struct PassPlanIn {
     uint32_t per_stream = 0;    // PT_PER_STREAM (0: default)
     uint32_t wave_stack = 0;    // PT_WAVE_STACK (0: kWaveStackMax)
     uint32_t n_cus = 0;         // compute units of the device (0: unknown - no whole-rounds nudge)
+    uint32_t groups_per_cu = 4; // workgroups of the pass kernel a compute unit holds at a time (its waves per SIMD)
     size_t stack_budget = 0;    // stack_form, default pass: bytes the streams' stacks may take (0: unbounded)
 };
 struct PassPlan {

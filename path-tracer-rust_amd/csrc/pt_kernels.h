@@ -8,6 +8,17 @@
 namespace pt {
 
 constexpr uint32_t kBlockBvh = 256;  // workgroup of the intersect kernel of scenes with a BVH
+// waves per SIMD (= workgroups per compute unit) k_pass_cand is compiled for, without walks (pt_kernels_flat.hip) and with: its
+// __launch_bounds__, launch_pass's LDS budget per workgroup and plan_pass's rounds of resident workgroups follow them
+#ifndef PT_CAND_WAVES
+#define PT_CAND_WAVES 5
+#endif
+#ifndef PT_SAMPLE_MAJOR
+#define PT_SAMPLE_MAJOR 1  // k_pass_cand: a trip's 64 primary rays are consecutive samples of one pixel (0: one sample of 64 pixels)
+#endif
+#ifndef PT_CAND_BVH_WAVES
+#define PT_CAND_BVH_WAVES 4
+#endif
 constexpr uint32_t kLevels = 13;    // ray depths 0..11 plus the (always empty) level written by the last shade
 // (kBlock, kMaxStreamPixels, kRayBytes, the wave-stack sizes and queue_bytes: pt_device.h - the pass planner of pt_host.cpp
 // needs them without the HIP headers)

@@ -111,6 +111,7 @@ __device__ __forceinline__ void load_ray_slice(const StreamSlice &q, uint32_t i,
     word = __float_as_uint(tp.w);
 }
 
+#ifndef PT_TU_FLAT  // (the translation unit of k_pass_cand without walks - pt_kernels_flat.hip - holds nothing else)
 // ------------------------------------------------------------------------------------------------
 template <bool PROBE>
 __global__ __launch_bounds__(kBlock) void k_generate(FrameParams F, RayQueue q, uint32_t *__restrict__ cnt0,
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_intersect_cand(DevScene S, RayQue
     if (tid == 0) blk_rays[b] += n;
 }
 
+#endif  // PT_TU_FLAT
 // ------------------------------------------------------------------------------------------------
 // radiance of the stream's own pixels, summed in LDS (u64 32.32 fixed point, [3][m])
 __device__ __forceinline__ void add_radiance_lds(unsigned long long *lds_acc, uint32_t m, uint32_t slot, vec3 v) {
@@ -304,6 +306,7 @@ __device__ __forceinline__ void add_radiance_lds(unsigned long long *lds_acc, ui
     if (bl) atomicAdd(&lds_acc[2u * m + slot], (unsigned long long)bl);
 }
 
+#ifndef PT_TU_FLAT
 __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, ShadeParams F, RayQueue qin, RayQueue qout,
                                                   const float2 *__restrict__ hit,
                                                   const uint32_t *__restrict__ cnt_in,
@@ -588,6 +591,7 @@ __global__ __launch_bounds__(kBlock, 6) void k_pass(DevScene S, FrameParams F, R
     }
 }
 
+#endif  // PT_TU_FLAT
 // ------------------------------------------------------------------------------------------------
 // k_pass with the candidate scan (pt_device.h: "Candidate scan") and WITHOUT LEVELS: a ray is FINISHED one chunk after it was
 // started, and the rays that wait for their next bounce live on a stack of the wave (see "THE WAVE'S RAY STACK" in the body).
@@ -629,7 +633,7 @@ static_assert(kCandWalkKeyBytes % 16u == 0u && sizeof(WalkNode) % 16u == 0u, "pe
 // (The workgroup's own copy of the nodes in LDS, in front of the stacks, was tried: mesh.json's 141 nodes are 9 KB, which
 // leaves room for three workgroups per CU instead of four - 16.1 against 17.8 G bounces/s.)
 template <bool STAGED, bool DEFER, bool BVH, bool PROBE, bool NLDS = false>
-__global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams F, RayQueue q0, RayQueue q1, uint32_t cap,
+__global__ __launch_bounds__(kBlock, BVH ? PT_CAND_BVH_WAVES : PT_CAND_WAVES) void k_pass_cand(DevScene S, FrameParams F, RayQueue q0, RayQueue q1, uint32_t cap,
                                                          uint32_t s0, uint32_t s_here, uint32_t m,
                                                          unsigned long long *__restrict__ acc,
                                                          unsigned long long *__restrict__ blk_rays,
@@ -664,19 +668,38 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
         lds_px[j] = pix % F.width;
         lds_py[j] = F.height - 1u - pix / F.width;
     }
-    // THE WAVES OF A WORKGROUP DO NOT WAIT FOR EACH OTHER: every wave traces a contiguous quarter of the stream's primary rays
+    // THE WAVES OF A WORKGROUP DO NOT WAIT FOR EACH OTHER: every wave traces a quarter of the stream's primary rays
     // on its own, its waiting rays on a stack of its own (below) - no workgroup barrier between the first one (LDS tables in
     // place) and the last (accumulators complete).  The workgroup shares the stream's pixel accumulators (LDS atomics) and
     // the staged scene records.
-    // Primary ray g of the stream is (pixel g % mb, sample g / mb); a lane's primaries are 64 apart, so its (pixel, sample)
-    // advance by (64 % mb, 64 / mb) with a carry - no division per trip.
+    // The stream's chunks of 64 primary rays are dealt to the four waves in turn (chunk c to wave c % 4), so that every wave gets
+    // its share of every pixel: with a contiguous quarter each and SAMPLE-MAJOR order (below) a wave would own whole pixels, and
+    // the waves of a workgroup, whose pixels' paths differ in length, would finish far apart.  A lane's primaries are 256 apart,
+    // so its (pixel, sample) advance by a fixed step with a carry - no division per trip.
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const uint32_t cap_w = cap >> 2;
-    const uint32_t n0 = mb * s_here;         // primary rays of the stream
-    const uint32_t quarter = (n0 + 3u) >> 2;  // ... of a wave (the last may have fewer)
-    const uint32_t base0 = wv * quarter < n0 ? wv * quarter : n0;
-    const uint32_t step_q = 64u / mb, step_r = 64u % mb;
+    const uint32_t n0 = mb * s_here;                        // primary rays of the stream
+    const uint32_t n_chunks = (n0 + 63u) >> 6;
+    const uint32_t my_chunks = (n_chunks + 3u - wv) >> 2;   // chunks wv, wv + 4, ...
+    const uint32_t quarter = (((n_chunks + 3u) >> 2) << 6) < n0 ? (((n_chunks + 3u) >> 2) << 6) : n0;  // upper bound of a wave's primaries
+    const uint32_t base0 = wv << 6;
+    uint32_t gen_left = 0u;                                 // primary rays this wave has still to start
+    if (my_chunks != 0u) {
+        const uint32_t last = wv + ((my_chunks - 1u) << 2);  // the wave's last chunk (the stream's last one may be partial)
+        gen_left = ((my_chunks - 1u) << 6) + (n0 - (last << 6) < 64u ? n0 - (last << 6) : 64u);
+    }
+#if PT_SAMPLE_MAJOR
+    // SAMPLE-MAJOR: primary ray g is (pixel g / s_here, sample g % s_here) - the 64 rays a trip starts are consecutive samples of
+    // one pixel (or of a few, when a pass has fewer than 64 samples per pixel).  They leave the camera nearly alike, hit the same
+    // object, and - the stack being last in, first out - their descendants are popped together: the blocks only some materials
+    // need (the refraction body, the second ray of a split, mirror reflection, emitter adds) run in few trips with many lanes
+    // instead of in nearly every trip with four.
+    const uint32_t step_q = 256u / s_here, step_r = 256u % s_here;
+    uint32_t gen_pj = (base0 + lane) / s_here, gen_sj = (base0 + lane) % s_here;
+#else  // primary ray g is (pixel g % mb, sample g / mb): a trip starts one sample of 64 pixels (rounds 1-3)
+    const uint32_t step_q = 256u / mb, step_r = 256u % mb;
     uint32_t gen_pj = (base0 + lane) % mb, gen_sj = (base0 + lane) / mb;
+#endif
     CandLds cand;
     const SurfRec *surf_lds = nullptr;
     uint32_t surf_head = 0u;
@@ -861,7 +884,6 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
     PT_PHASE(kPhBarrier);
     __syncthreads();  // accumulators, pixel tables and staged records are in place
     PT_PHASE(kPhOther);
-    uint32_t gen_left = (n0 - base0) < quarter ? (n0 - base0) : quarter;  // primary rays this wave has still to start
     uint32_t par = 0u;                      // the slots (LDS) of the chunk started in this trip
     bool pending = false;                   // wave-uniform: the chunk started in the trip before waits to be finished
     vec3 prev_thr = mk(0.0f, 0.0f, 0.0f);   // what the ray started in the trip before still needs from registers
@@ -915,12 +937,21 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
                     in = PROBE ? primary_ray<PROBE>(F, lds_pix[pj], s0 + sj) : primary_ray_at(Fl, lds_pix[pj], lds_px[pj], lds_py[pj], s0 + sj);
                     word = pack_word(pj, sj, PROBE ? F.depth0 : 0u, 1u);
                 }
+#if PT_SAMPLE_MAJOR
+                gen_sj += step_r;
+                gen_pj += step_q;
+                if (gen_sj >= s_here) {
+                    gen_sj -= s_here;
+                    gen_pj += 1u;
+                }
+#else
                 gen_pj += step_r;
                 gen_sj += step_q;
                 if (gen_pj >= mb) {
                     gen_pj -= mb;
                     gen_sj += 1u;
                 }
+#endif
                 gen_left = rfl(gen_left - cnt);
             } else {
                 PT_PHASE(kPhLoad);
@@ -1061,6 +1092,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_pass_cand(DevScene S, FrameParams
 #endif
 }
 
+#ifndef PT_TU_FLAT
 // ------------------------------------------------------------------------------------------------
 // k_pass for scenes with a BVH: the same one-launch-per-pass walk of a stream, with the BVH walks of k_intersect<true>:
 // the scan skips them (gates exact, first step of the walk taken from SGPRs), a ray that needs one is parked per wave
@@ -2004,6 +2036,49 @@ void launch_shade(hipStream_t st, uint32_t K, const DevScene &S, const FramePara
     hipLaunchKernelGGL(k_shade, dim3(K), dim3(kBlock), lds, st, S, P, qin, qout, hit, cnt_in, cnt_out, cap, acc,
                        flags, m);
 }
+#endif  // PT_TU_FLAT
+// k_pass_cand for one pass: the workgroup's LDS (`lds` bytes) is laid out by launch_pass (below); the instances WITHOUT walks
+// are compiled in a translation unit of their own (pt_kernels_flat.hip: PT_CAND_WAVES waves per SIMD and the instruction
+// scheduling that fits them - the Makefile says which and why), the instances with walks here.
+#define PT_LAUNCH_CAND(ST, DF, BV, NL)                                                                                 \
+    do {                                                                                                               \
+        if (F.probe)                                                                                                   \
+            PT_LAUNCH_CAND2(ST, DF, BV, true, NL);                                                                     \
+        else                                                                                                           \
+            PT_LAUNCH_CAND2(ST, DF, BV, false, NL);                                                                    \
+    } while (0)
+// (more than 64 KB of dynamic LDS - wide deep trees with hundreds of pixels per stream - has to be asked for)
+#define PT_LAUNCH_CAND2(ST, DF, BV, PR, NL)                                                                               \
+    do {                                                                                                               \
+        if (lds > 64u * 1024u) {                                                                                       \
+            const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pass_cand<ST, DF, BV, PR, NL>), \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+            if (ea != hipSuccess) {                                                                                    \
+                set_error("k_pass_cand needs " + std::to_string(lds) + " bytes of LDS per workgroup for this scene: " +  \
+                          hipGetErrorString(ea));                                                                      \
+                return ea;                                                                                             \
+            }                                                                                                          \
+        }                                                                                                              \
+        hipLaunchKernelGGL((k_pass_cand<ST, DF, BV, PR, NL>), dim3(K), dim3(kBlock), lds, st, S2, F, q0, q1, cap, s0, s_here, m, acc, blk_rays, flags); \
+    } while (0)
+hipError_t launch_pass_cand_flat(hipStream_t st, uint32_t K, const DevScene &S2, const FrameParams &F, const RayQueue &q0,
+                                 const RayQueue &q1, uint32_t cap, uint32_t s0, uint32_t s_here, uint32_t m, unsigned long long *acc,
+                                 unsigned long long *blk_rays, uint32_t *flags, size_t lds, bool staged, bool defer);
+#ifdef PT_TU_FLAT
+hipError_t launch_pass_cand_flat(hipStream_t st, uint32_t K, const DevScene &S2, const FrameParams &F, const RayQueue &q0,
+                                 const RayQueue &q1, uint32_t cap, uint32_t s0, uint32_t s_here, uint32_t m, unsigned long long *acc,
+                                 unsigned long long *blk_rays, uint32_t *flags, size_t lds, bool staged, bool defer) {
+    if (staged && defer)
+        PT_LAUNCH_CAND(true, true, false, false);
+    else if (staged)
+        PT_LAUNCH_CAND(true, false, false, false);
+    else if (defer)
+        PT_LAUNCH_CAND(false, true, false, false);
+    else
+        PT_LAUNCH_CAND(false, false, false, false);
+    return hipSuccess;
+}
+#else
 hipError_t launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const FrameParams &F, const RayQueue &q0,
                        const RayQueue &q1, uint32_t cap, uint32_t s0, uint32_t s_here, uint32_t m, unsigned long long *acc,
                        unsigned long long *blk_rays, uint32_t *flags) {
@@ -2013,10 +2088,10 @@ hipError_t launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const Fram
     const size_t lds_plain = pass_lds_defer_offset(m);
     const size_t lds_defer = lds_plain + (size_t)(kBlock / 64u) * 3u * kDeferCap * sizeof(float4);
     if (S.cand_scan) {
-        // candidate scan: ray slots, keys and ring per wave, the (smaller) deferral buffers while four workgroups still fit
-        // a CU (40 KiB each; the kernel is built for four waves per SIMD), + the workgroup's copy of the candidate records
-        const size_t budget = 40u * 1024u;
+        // candidate scan: ray slots, keys and ring per wave + the workgroup's copy of the candidate and shading records while
+        // as many workgroups still fit a CU's 160 KiB as the kernel is built to run waves per SIMD (with walks four: 40 KiB each)
         const bool bvh = S.n_bvh_nodes != 0u;
+        const size_t budget = 160u * 1024u / (bvh ? PT_CAND_BVH_WAVES : PT_CAND_WAVES);
         DevScene S2 = S;
         S2.bvh_in_lds &= ~1u;  // (nodes from global memory: PT_BVH_LDS asks for the staged k_intersect, not for this kernel)
         const size_t rec_cand = (size_t)S.n_cand_pairs * sizeof(CandPairRec);
@@ -2024,8 +2099,7 @@ hipError_t launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const Fram
         // glass deferral: not with walks (their queues take its place in LDS; a walked ray is shaded in place anyway)
         // (Without levels the deferral no longer pays: a chunk mixes rays of every depth and nearly every trip shades some glass
         // anyway - shading it in place, 46.5 against 46.05 G bounces/s on cornell, builds alternated; PT_GLASS_DEFER=1 brings
-        // the buffers back for that comparison.  Five waves per SIMD in the LDS this frees: 96 VGPRs with 91 values spilled,
-        // 26.3 G.)
+        // the buffers back for that comparison.)
         const bool defer = !bvh && S.glass_defer_ok;  // (the scene has glass and the context holds parking areas: pt_api.hip)
         // walks: the nodes of a small tree are staged in LDS beside (smaller) walk queues when they fit with the candidate
         // records (mesh.json: 171 nodes, 10.9 KB: up to 24 pixels per stream).  Measured: no gain and no loss against the
@@ -2051,43 +2125,13 @@ hipError_t launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const Fram
             S2.surf_head = (uint32_t)(fit < n_ranks ? fit : n_ranks);
         }
         const size_t lds = before + (staged ? rec_cand + (S2.surf_staged ? rec_surf : (size_t)S2.surf_head * sizeof(SurfRec)) : 0u);
-        // (more than 64 KB of dynamic LDS - wide deep trees with hundreds of pixels per stream - has to be asked for)
-#define PT_LAUNCH_CAND(ST, DF, BV, NL)                                                                                 \
-    do {                                                                                                               \
-        if (F.probe)                                                                                                   \
-            PT_LAUNCH_CAND2(ST, DF, BV, true, NL);                                                                     \
-        else                                                                                                           \
-            PT_LAUNCH_CAND2(ST, DF, BV, false, NL);                                                                    \
-    } while (0)
-#define PT_LAUNCH_CAND2(ST, DF, BV, PR, NL)                                                                               \
-    do {                                                                                                               \
-        if (lds > 64u * 1024u) {                                                                                       \
-            const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pass_cand<ST, DF, BV, PR, NL>), \
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
-            if (ea != hipSuccess) {                                                                                    \
-                set_error("k_pass_cand needs " + std::to_string(lds) + " bytes of LDS per workgroup for this scene: " +  \
-                          hipGetErrorString(ea));                                                                      \
-                return ea;                                                                                             \
-            }                                                                                                          \
-        }                                                                                                              \
-        hipLaunchKernelGGL((k_pass_cand<ST, DF, BV, PR, NL>), dim3(K), dim3(kBlock), lds, st, S2, F, q0, q1, cap, s0, s_here, m, acc, blk_rays, flags); \
-    } while (0)
-        if (bvh && staged && nodes_lds)
+        if (!bvh) return launch_pass_cand_flat(st, K, S2, F, q0, q1, cap, s0, s_here, m, acc, blk_rays, flags, lds, staged, defer);
+        if (staged && nodes_lds)
             PT_LAUNCH_CAND(true, false, true, true);
-        else if (bvh && staged)
-            PT_LAUNCH_CAND(true, false, true, false);
-        else if (bvh)
-            PT_LAUNCH_CAND(false, false, true, false);
-        else if (staged && defer)
-            PT_LAUNCH_CAND(true, true, false, false);
         else if (staged)
-            PT_LAUNCH_CAND(true, false, false, false);
-        else if (defer)
-            PT_LAUNCH_CAND(false, true, false, false);
+            PT_LAUNCH_CAND(true, false, true, false);
         else
-            PT_LAUNCH_CAND(false, false, false, false);
-#undef PT_LAUNCH_CAND
-#undef PT_LAUNCH_CAND2
+            PT_LAUNCH_CAND(false, false, true, false);
         return hipSuccess;
     }
     if (lds_defer <= 32u * 1024u) {
@@ -2103,6 +2147,10 @@ hipError_t launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const Fram
     }
     return hipSuccess;
 }
+#endif  // PT_TU_FLAT
+#undef PT_LAUNCH_CAND
+#undef PT_LAUNCH_CAND2
+#ifndef PT_TU_FLAT
 void launch_pass_bvh(hipStream_t st, uint32_t K, const DevScene &S, const FrameParams &F, const RayQueue &q0,
                      const RayQueue &q1, uint32_t cap, uint32_t s0, uint32_t s_here, uint32_t m, unsigned long long *acc,
                      unsigned long long *blk_rays, uint32_t *flags) {
@@ -2194,4 +2242,5 @@ void launch_numerics(hipStream_t st, const float *in, uint32_t n, float *out_sin
                        out_rcp, out_philox);
 }
 
+#endif  // PT_TU_FLAT
 }  // namespace pt
