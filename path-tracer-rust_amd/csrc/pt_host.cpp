@@ -709,7 +709,7 @@ int plan_pass(const PassPlanIn &in, PassPlan &out, uint64_t *want_next) {
     // (round 4, with the walk queue over the four-wide tree: scenes with walks a little shorter - mesh.json 1024x768 @1024,
     // 18 Ki primaries per stream 29.0, 20 Ki 29.1, 21-22 Ki 29.2, 24 Ki 28.7, 32 Ki 28.5 G bounces/s; cornell.json is flat from 12 Ki to
     // 48 Ki: 47.2-47.7)
-    const uint64_t per_stream = in.stack_form ? (uint64_t)(in.per_stream ? in.per_stream : (in.has_bvh ? 22528u : 24576u))
+    const uint64_t per_stream = in.stack_form ? (uint64_t)(in.per_stream ? in.per_stream : (in.has_bvh ? 22528u : 16384u))
                                               : (in.has_bvh ? 4096u : 2048u);
     uint64_t k_target = (npix * spp_pass + per_stream - 1u) / per_stream;
     if (k_target < 2048u) k_target = 2048u;

@@ -13,6 +13,9 @@ constexpr uint32_t kBlockBvh = 256;  // workgroup of the intersect kernel of sce
 #ifndef PT_CAND_WAVES
 #define PT_CAND_WAVES 5
 #endif
+#ifndef PT_MEGA_WAVES
+#define PT_MEGA_WAVES 4  // k_mega_cand without walks
+#endif
 #ifndef PT_SAMPLE_MAJOR
 #define PT_SAMPLE_MAJOR 1  // k_pass_cand: a trip's 64 primary rays are consecutive samples of one pixel (0: one sample of 64 pixels)
 #endif

@@ -1447,7 +1447,7 @@ constexpr uint32_t kMegaItemChunk = 32;
 __host__ __device__ inline size_t mega_stack_bytes(uint32_t lanes) { return (size_t)lanes * kMegaStackEntries * 40u; }
 
 template <bool BVH, bool PROBE>
-__global__ __launch_bounds__(kBlock, 4) void k_mega_cand(DevScene S, FrameParams F, unsigned long long *__restrict__ acc,
+__global__ __launch_bounds__(kBlock, BVH ? 4 : PT_MEGA_WAVES) void k_mega_cand(DevScene S, FrameParams F, unsigned long long *__restrict__ acc,
                                                          uint32_t s_begin, uint32_t s_end, uint32_t lane_spp, uint32_t n_split,
                                                          unsigned long long *__restrict__ total_rays, MegaStack stk, uint32_t spare_off,
                                                          uint32_t n_spare_max, uint32_t surf_off) {

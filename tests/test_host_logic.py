@@ -306,10 +306,10 @@ PLAN_SRC = r"""
 #include "ptrace.h"
 #include "pt_host.h"
 using namespace pt;
-// argv: npix spp want default(0/1) stack_form stack_park cand_scan has_bvh streams per_stream wave_stack n_cus budget
+// argv: npix spp want default(0/1) stack_form stack_park cand_scan has_bvh streams per_stream wave_stack n_cus budget groups_per_cu
 // prints the plan after following plan_pass's retries the way render_wavefront does: OK spp_pass m K cap bytes0 bytes1 retries
 int main(int argc, char **argv) {
-    if (argc != 14) return 2;
+    if (argc != 15) return 2;
     host::PassPlanIn in;
     in.npix = strtoull(argv[1], 0, 10);
     in.spp = (uint32_t)strtoul(argv[2], 0, 10);
@@ -324,6 +324,7 @@ int main(int argc, char **argv) {
     in.wave_stack = (uint32_t)strtoul(argv[11], 0, 10);
     in.n_cus = (uint32_t)strtoul(argv[12], 0, 10);
     in.stack_budget = (size_t)strtoull(argv[13], 0, 10);
+    in.groups_per_cu = (uint32_t)strtoul(argv[14], 0, 10);
     host::PassPlan p;
     int retries = 0;
     for (;;) {
@@ -352,16 +353,18 @@ def test_pass_plan(tmp_path):
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ptlib.PKG, "csrc"), "-I", os.path.join(ptlib.ROOT, "include"),
                            str(src), "-o", exe, "-L", ptlib.PKG, "-lptrace_hip", "-Wl,-rpath," + ptlib.PKG])
 
-    def plan(npix, spp, want, default=1, stack=1, park=0, cand=1, bvh=0, streams=0, per_stream=0, wave_stack=0, n_cus=256, budget=0):
+    def plan(npix, spp, want, default=1, stack=1, park=0, cand=1, bvh=0, streams=0, per_stream=0, wave_stack=0, n_cus=256, budget=0, groups=None):
+        groups = groups or (4 if bvh or not stack else 5)  # workgroups a CU holds: k_pass_cand without walks runs five waves per SIMD
         out = subprocess.check_output([exe] + [str(v) for v in (npix, spp, want, default, stack, park, cand, bvh, streams, per_stream,
-                                                                wave_stack, n_cus, budget)]).decode().split()
+                                                                wave_stack, n_cus, budget, groups)]).decode().split()
         if out[0] != "OK":
             return out[0]
         spp_pass, m, K, cap, b0, b1, retries = map(int, out[1:])
         assert K * m >= npix > (K - 1) * m and 1 <= m <= 1024 and 1 <= spp_pass <= spp and cap % 4 == 0
         if stack:
             w = cap // 4
-            assert w & (w - 1) == 0 and 128 <= w <= 1024 and (m * spp_pass + 8 <= w or w == (wave_stack or 1024))
+            most = min(m * spp_pass, -(-(-(-m * spp_pass // 64)) // 4) * 64)  # primaries of the wave with the most chunks of 64
+            assert w & (w - 1) == 0 and 128 <= w <= 1024 and (4 * most + 3 <= w or w == (wave_stack or 1024))
             assert b0 == K * cap * 40 and b1 == (K * 4 * 128 * 48 if park else 0)
         else:
             assert cap >= 4 * m * spp_pass + 16 and cap % 256 == 0 and b0 == b1 == K * cap * 40
@@ -370,7 +373,8 @@ def test_pass_plan(tmp_path):
     npix = 1024 * 768
     spp_pass, m, K, cap, _ = plan(npix, 4096, 512 << 20)
     assert spp_pass == 683 and cap == 4096 and -(-4096 // spp_pass) == 6 and 4096 - 5 * spp_pass > 600  # six equal passes
-    assert (m, K) == (32, 24576)  # streams of about 24 Ki primaries (36 pixels), nudged to whole rounds of 1024 resident workgroups
+    assert (m, K) == (22, 35747)  # streams of about 16 Ki primaries (24 pixels), nudged to the fewest rounds of 1280 resident workgroups x pixels
+    assert plan(npix, 4096, 512 << 20, groups=4)[1:3] == (24, 32768)  # (rounds of 1024: 32.0)
     spp_pass, m, K, cap, _ = plan(npix, 1024, 512 << 20, park=1, bvh=1)  # mesh.json: two passes of 512, streams of 22 Ki primaries for scenes with walks, no nudge
     assert spp_pass == 512 and m == -(-npix // -(-npix * 512 // 22528)) and cap == 4096
     spp_pass, m, K, cap, _ = plan(npix, 128, 512 << 20)  # few samples: one pass, short streams of at most 64 (+ nudge) pixels

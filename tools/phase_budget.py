@@ -16,7 +16,8 @@ def correct(path, shipped_rate, pmc_lanes=None):
     of stamps, is what one stamp costs a wave, and a phase's corrected cycles are its stamped cycles minus its entries
     times that.  python tools/phase_budget.py --correct <budget.json> <shipped bounces/s>"""
     res = json.load(open(path))
-    waves_per_chip = 256 * 4 * 4  # SIMDs x waves per SIMD (k_pass_cand's occupancy)
+    # SIMDs x waves per SIMD: k_pass_cand runs five waves per SIMD without walks, four with (csrc/pt_kernels.h)
+    waves_per_chip = 256 * 4 * (4 if "bvh" in res.get("kernel", "") else 5)
     shipped_cyc = waves_per_chip * res["in_kernel_clock_ghz"] * 1e9 / shipped_rate * 64.0  # wave-cycles per 64 bounces
     stamps = sum(p["entries_per_kbounce"] for p in res["phases"].values()) * 0.064
     per_stamp = (res["wave_cycles_per_bounce"] - shipped_cyc) / stamps
