@@ -198,8 +198,8 @@ int pt_bvh_refs_fit(uint64_t n_bvh_nodes, uint64_t n_pair_records);
 
 /* Device memory the wavefront backend may take for its ray queues in this context (bytes; 0 = the default: 85 % of what
  * the device reports free, divided among the contexts one call creates on it).  The default kernel (k_pass_cand) keeps
- * each wave's waiting rays on a stack of at most 1024 slots: K streams x 4 waves x 40 KB, whatever the pass holds (4.0 GB
- * for the 24 576 streams of a 1024x768 pass of 683 samples; small passes need less); the level-by-level forms (PT_FLAG_SEPARATE_KERNELS,
+ * each wave's waiting rays on a stack of at most 1024 slots: K streams x 4 waves x 40 KB, whatever the pass holds (5.9 GB
+ * for the 35 747 streams of a 1024x768 pass of 683 samples; small passes need less); the level-by-level forms (PT_FLAG_SEPARATE_KERNELS,
  * PT_FLAG_NO_BVH, PT_CAND_SCAN=0) hold rays_per_pass primary rays at 352 B each, 36 GB at their default.  A pass that does
  * not fit is halved until it does (a failed allocation does the same), which changes how the samples are batched and
  * nothing in the image.  A figure set here also bounds an explicit pt_config.rays_per_pass (the budget wins); without one

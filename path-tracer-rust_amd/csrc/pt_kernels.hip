@@ -612,7 +612,12 @@ constexpr uint32_t kCandParkCap = kWaveParkCap;  // 63 left over + 64 new at mos
 // per wave: the walk queue (header + 8-byte entries: box tests from one end, leaves from the other), which is also where
 // the depth-first stacks (DevScene.bvh_stack entries x 64 lanes x u16, or u32 when a tree has 32 768 nodes or leaves) and
 // the leaf list of the rare second walk live
-constexpr uint32_t kWalkQueueBytes = 2560;        // 320 entries
+// (448 entries.  With sample-major primary rays the walkers of a session are alike and their items crowd the queue together: at
+// 320 entries one wave-walk in fifty dropped pushes - those rays walk again depth-first - at 448 mesh.json gains 1.4 %; 512: the same)
+#ifndef PT_WALK_QUEUE_BYTES
+#define PT_WALK_QUEUE_BYTES 3584
+#endif
+constexpr uint32_t kWalkQueueBytes = PT_WALK_QUEUE_BYTES;
 constexpr uint32_t kWalkQueueBytesStaged = 2048;  // 256 entries: beside the workgroup's copy of the nodes (bvh_in_lds bit 2)
 __host__ __device__ inline size_t pass_cand_queue_bytes(const DevScene &S) {
     const size_t again = (size_t)S.bvh_stack * 64u * ((S.bvh_in_lds & 2u) ? 2u : 4u) + kLeafListCap * 4u;
