@@ -13,6 +13,9 @@ constexpr uint32_t kBlockBvh = 256;  // workgroup of the intersect kernel of sce
 #ifndef PT_CAND_WAVES
 #define PT_CAND_WAVES 5
 #endif
+#ifndef PT_ISECT_WAVES
+#define PT_ISECT_WAVES 4  // k_intersect_cand (the flat unit's too)
+#endif
 #ifndef PT_MEGA_WAVES
 #define PT_MEGA_WAVES 4  // k_mega_cand without walks
 #endif
@@ -44,6 +47,8 @@ void launch_pass_bvh(hipStream_t st, uint32_t K, const DevScene &S, const FrameP
                      unsigned long long *blk_rays, uint32_t *flags);
 void launch_generate(hipStream_t st, uint32_t K, const FrameParams &F, const RayQueue &q, uint32_t *cnt0,
                      uint32_t cap, uint32_t s0, uint32_t s_here, uint32_t m);
+void launch_intersect_cand(hipStream_t st, uint32_t K, const DevScene &S, const RayQueue &q, float2 *hit, const uint32_t *cnt,
+                           uint32_t cap, unsigned long long *blk_rays);  // (pt_kernels_flat.hip)
 void launch_intersect(hipStream_t st, uint32_t K, const DevScene &S, const RayQueue &q, float2 *hit,
                       const uint32_t *cnt, uint32_t cap, unsigned long long *blk_rays);
 void launch_shade(hipStream_t st, uint32_t K, const DevScene &S, const FrameParams &F, const RayQueue &qin,

@@ -215,6 +215,7 @@ __global__ __launch_bounds__(BVH ? kBlockBvh : kBlock, BVH ? 5 : 1) void k_inter
     if (tid == 0) blk_rays[b] += n;
 }
 
+#endif  // PT_TU_FLAT (k_intersect_cand below is the flat unit's too)
 // ------------------------------------------------------------------------------------------------
 // The stand-alone intersect step with the CANDIDATE SCAN of k_pass_cand (pt_device.h: "Candidate scan"; scenes without BVH
 // meshes): intersect_scene (mod.rs:631-659) for every ray of a stream, as its own kernel - 24 B of ray in, 8 B of hit
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(BVH ? kBlockBvh : kBlock, BVH ? 5 : 1) void k_inter
 __host__ __device__ constexpr size_t intersect_cand_lds_bytes() { return (size_t)(kBlock / 64u) * kCandWaveBytes; }
 
 template <bool STAGED>
-__global__ __launch_bounds__(kBlock, 4) void k_intersect_cand(DevScene S, RayQueue q, float2 *__restrict__ hit,
+__global__ __launch_bounds__(kBlock, PT_ISECT_WAVES) void k_intersect_cand(DevScene S, RayQueue q, float2 *__restrict__ hit,
                                                               const uint32_t *__restrict__ cnt, uint32_t cap,
                                                               unsigned long long *__restrict__ blk_rays) {
     const uint32_t b = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
@@ -296,7 +297,6 @@ __global__ __launch_bounds__(kBlock, 4) void k_intersect_cand(DevScene S, RayQue
     if (tid == 0) blk_rays[b] += n;
 }
 
-#endif  // PT_TU_FLAT
 // ------------------------------------------------------------------------------------------------
 // radiance of the stream's own pixels, summed in LDS (u64 32.32 fixed point, [3][m])
 __device__ __forceinline__ void add_radiance_lds(unsigned long long *lds_acc, uint32_t m, uint32_t slot, vec3 v) {
@@ -2011,13 +2011,7 @@ void launch_intersect(hipStream_t st, uint32_t K, const DevScene &S, const RayQu
         hipLaunchKernelGGL(k_intersect<true>, dim3(K), dim3(kBlockBvh),
                            bvh_park_offset(S, kBlockBvh) + bvh_park_bytes(kBlockBvh), st, S, q, hit, cnt, cap, blk_rays);
     } else if (S.cand_scan) {  // the candidate scan (PT_CAND_SCAN=0 / PT_FLAG_NO_BVH: the every-triangle scan below)
-        const size_t rec = (size_t)S.n_cand_pairs * sizeof(CandPairRec);
-        if (intersect_cand_lds_bytes() + rec <= 40u * 1024u)
-            hipLaunchKernelGGL(k_intersect_cand<true>, dim3(K), dim3(kBlock), intersect_cand_lds_bytes() + rec, st, S, q, hit, cnt,
-                               cap, blk_rays);
-        else
-            hipLaunchKernelGGL(k_intersect_cand<false>, dim3(K), dim3(kBlock), intersect_cand_lds_bytes(), st, S, q, hit, cnt, cap,
-                               blk_rays);
+        launch_intersect_cand(st, K, S, q, hit, cnt, cap, blk_rays);
     } else {
         hipLaunchKernelGGL(k_intersect<false>, dim3(K), dim3(kBlock), 0, st, S, q, hit, cnt, cap, blk_rays);
     }
@@ -2070,6 +2064,17 @@ hipError_t launch_pass_cand_flat(hipStream_t st, uint32_t K, const DevScene &S2,
                                  const RayQueue &q1, uint32_t cap, uint32_t s0, uint32_t s_here, uint32_t m, unsigned long long *acc,
                                  unsigned long long *blk_rays, uint32_t *flags, size_t lds, bool staged, bool defer);
 #ifdef PT_TU_FLAT
+// the stand-alone intersect step with the candidate scan (PT_FLAG_SEPARATE_KERNELS, scenes without BVH meshes)
+void launch_intersect_cand(hipStream_t st, uint32_t K, const DevScene &S, const RayQueue &q, float2 *hit, const uint32_t *cnt,
+                           uint32_t cap, unsigned long long *blk_rays) {
+    const size_t rec = (size_t)S.n_cand_pairs * sizeof(CandPairRec);
+    if (intersect_cand_lds_bytes() + rec <= 160u * 1024u / PT_ISECT_WAVES)
+        hipLaunchKernelGGL(k_intersect_cand<true>, dim3(K), dim3(kBlock), intersect_cand_lds_bytes() + rec, st, S, q, hit, cnt,
+                           cap, blk_rays);
+    else
+        hipLaunchKernelGGL(k_intersect_cand<false>, dim3(K), dim3(kBlock), intersect_cand_lds_bytes(), st, S, q, hit, cnt, cap,
+                           blk_rays);
+}
 hipError_t launch_pass_cand_flat(hipStream_t st, uint32_t K, const DevScene &S2, const FrameParams &F, const RayQueue &q0,
                                  const RayQueue &q1, uint32_t cap, uint32_t s0, uint32_t s_here, uint32_t m, unsigned long long *acc,
                                  unsigned long long *blk_rays, uint32_t *flags, size_t lds, bool staged, bool defer) {

@@ -968,7 +968,7 @@ def test_random_scenes_against_oracle(gpu):
     total = 0
     for k in range(int(os.environ.get("PT_FUZZ_SCENES", "40"))):  # one-off long runs: PT_FUZZ_SCENES=500 PT_FUZZ_SEED=...
         sc = _random_scene(rng, k)
-        w, h, spp = 40, 28, 6
+        w, h, spp = 40, 28, int(os.environ.get("PT_FUZZ_SPP", "6"))  # (PT_FUZZ_SPP=80: passes whose chunks of 64 primaries are one pixel's samples)
         want, cnt, _ = ptlib.oracle_render(sc, w, h, spp, 100 + k)
         ref_img = None
         for (backend, flags) in ((0, 0), (0, PT_FLAG_SEPARATE_KERNELS), (0, 1), (1, 0)):
