@@ -241,6 +241,40 @@ def test_many_passes_and_odd_sizes(gpu):
     assert np.array_equal(got1, got)  # the image does not depend on the pass size (integer accumulation)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("sid", ["cornell", "mesh"])
+def test_primary_ray_order_of_the_pass_kernel(gpu, sid):
+    """k_pass_cand starts its primary rays SAMPLE-MAJOR - a trip's 64 primaries are consecutive samples of one pixel - in chunks of 64
+    that are dealt to the workgroup's four waves in turn (csrc/pt_kernels.hip).  Which lane traces which (pixel, sample) must not
+    show anywhere: the frame is the megakernel's (its own, unrelated order) bit for bit and the bounce count the same, for passes
+    whose samples per pixel sit on every edge of that arithmetic - 1, just under / at / just over a chunk of 64, just under / at /
+    just over the four waves' 256, a prime - for frames of 1, 3, 22 and 23 pixels per stream, and for a stream count that leaves the
+    last streams a pixel short."""
+    L, ctx = gpu
+    sc = ptlib.load_scene_py(ptlib.scene_path(sid))
+    set_scene(gpu, sc)
+    cases = [(16, 8, 1, 0), (16, 8, 63, 0), (16, 8, 64, 0), (16, 8, 65, 0), (9, 7, 255, 0), (9, 7, 256, 0), (9, 7, 257, 0),
+             (9, 7, 683, 0), (31, 3, 130, 0), (64, 33, 67, 0), (40, 30, 97, 1), (40, 30, 300, 5)]
+    for (w, h, spp, per_pass) in cases:
+        npix = w * h
+        d_out = C.c_void_p()
+        assert L.pt_device_malloc(0, npix * 12, C.byref(d_out)) == 0
+        frames, bounces = [], []
+        for backend in (0, 1):
+            rpp = npix * per_pass if (per_pass and backend == 0) else 0  # (several passes: the last one shorter)
+            cfg = PtConfig(w, h, spp, backend, 77, 0, 0, rpp, 0)
+            st = PtStats()
+            assert L.pt_ctx_render(ctx, C.byref(cfg), d_out, None, None, None, None, C.byref(st)) == 0, L.pt_last_error()
+            host = np.zeros((npix, 3), dtype=np.float32)
+            assert L.pt_device_download(0, host.ctypes.data_as(C.c_void_p), d_out, npix * 12) == 0
+            frames.append(host)
+            bounces.append(st.ray_bounces)
+            assert st.samples == npix * spp
+        L.pt_device_free(0, d_out)
+        assert bounces[0] == bounces[1], (w, h, spp, bounces)
+        assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32)), (w, h, spp)
+
+
 def test_bands_equal_whole_frame(gpu):
     """Rendering the frame as N bands (what N ranks do) gives bit-identical pixels to one call."""
     sc = ptlib.load_scene_py(ptlib.scene_path("cornell"))
