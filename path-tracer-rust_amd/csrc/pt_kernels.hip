@@ -32,6 +32,8 @@
 // Queue arrays (per ray): od0 = (ox,oy,oz,dx) 16 B, od1 = (dy,dz) 8 B, tp = (throughput rgb, bookkeeping word) 16 B;
 // hit = (t, id) 8 B (three-kernel form only).  k_pass moves 40 B out + 40 B in per ray of depth >= 1; the separate
 // kernels 32 B/ray (intersect) and 48 B in + 40 B out per survivor (shade).
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include "pt_kernels.h"
@@ -2078,6 +2080,14 @@ void launch_intersect_cand(hipStream_t st, uint32_t K, const DevScene &S, const 
 hipError_t launch_pass_cand_flat(hipStream_t st, uint32_t K, const DevScene &S2, const FrameParams &F, const RayQueue &q0,
                                  const RayQueue &q1, uint32_t cap, uint32_t s0, uint32_t s_here, uint32_t m, unsigned long long *acc,
                                  unsigned long long *blk_rays, uint32_t *flags, size_t lds, bool staged, bool defer) {
+    // (diagnosis: PT_LDS_PAD=n asks for n bytes of LDS the kernel does not use - where does the fifth workgroup of a CU stop fitting?)
+    static const size_t lds_pad = getenv("PT_LDS_PAD") ? (size_t)atol(getenv("PT_LDS_PAD")) : 0u;
+    static bool said = false;
+    if (getenv("PT_LDS_PAD") && !said) {
+        said = true;
+        fprintf(stderr, "k_pass_cand: %zu bytes of LDS per workgroup (+ %zu of padding), m = %u\n", lds, lds_pad, m);
+    }
+    lds += lds_pad;
     if (staged && defer)
         PT_LAUNCH_CAND(true, true, false, false);
     else if (staged)
@@ -2101,7 +2111,8 @@ hipError_t launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const Fram
         // candidate scan: ray slots, keys and ring per wave + the workgroup's copy of the candidate and shading records while
         // as many workgroups still fit a CU's 160 KiB as the kernel is built to run waves per SIMD (with walks four: 40 KiB each)
         const bool bvh = S.n_bvh_nodes != 0u;
-        const size_t budget = 160u * 1024u / (bvh ? PT_CAND_BVH_WAVES : PT_CAND_WAVES);
+        // (measured with PT_LDS_PAD: four workgroups of 40 928 B share a CU, five of 32 144 B do, five of 32 400 B do not)
+        const size_t budget = 160u * 1024u / (bvh ? PT_CAND_BVH_WAVES : PT_CAND_WAVES) - (bvh ? 0u : 512u);
         DevScene S2 = S;
         S2.bvh_in_lds &= ~1u;  // (nodes from global memory: PT_BVH_LDS asks for the staged k_intersect, not for this kernel)
         const size_t rec_cand = (size_t)S.n_cand_pairs * sizeof(CandPairRec);
@@ -2134,8 +2145,14 @@ hipError_t launch_pass(hipStream_t st, uint32_t K, const DevScene &S, const Fram
             const size_t n_ranks = (size_t)S.n_objs + S.n_tris;
             S2.surf_head = (uint32_t)(fit < n_ranks ? fit : n_ranks);
         }
-        const size_t lds = before + (staged ? rec_cand + (S2.surf_staged ? rec_surf : (size_t)S2.surf_head * sizeof(SurfRec)) : 0u);
+        size_t lds = before + (staged ? rec_cand + (S2.surf_staged ? rec_surf : (size_t)S2.surf_head * sizeof(SurfRec)) : 0u);
+        if (bvh && getenv("PT_LDS_PAD")) lds += (size_t)atol(getenv("PT_LDS_PAD"));
         if (!bvh) return launch_pass_cand_flat(st, K, S2, F, q0, q1, cap, s0, s_here, m, acc, blk_rays, flags, lds, staged, defer);
+        static bool said = false;
+        if (getenv("PT_LDS_PAD") && !said) {
+            said = true;
+            fprintf(stderr, "k_pass_cand<BVH>: %zu bytes of LDS per workgroup (+ %ld of padding), m = %u, staged %d nodes_lds %d surf_head %u\n", lds, atol(getenv("PT_LDS_PAD")), m, (int)staged, (int)nodes_lds, S2.surf_head);
+        }
         if (staged && nodes_lds)
             PT_LAUNCH_CAND(true, false, true, true);
         else if (staged)
