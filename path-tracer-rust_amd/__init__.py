@@ -234,7 +234,7 @@ def kernel_isa_hash():
 # the -mllvm set the Makefile asks for (instruction placement only; worth 3.5 % on mesh.json): a library built without some of
 # them - its compiler did not know them - still renders the same images
 # (two sets, "general | flat: k_pass_cand without walks" - that kernel is a translation unit of its own, pt_kernels_flat.hip)
-BUILD_FLAGS_WANTED = ("-enable-post-misched=0", "-amdgpu-sched-strategy=max-ilp", "-disable-machine-licm", "-disable-machine-sink")
+BUILD_FLAGS_WANTED = ("-amdgpu-sched-strategy=max-ilp", "-disable-machine-licm", "-disable-machine-sink")
 BUILD_FLAGS_WANTED_FLAT = ("-amdgpu-sched-strategy=iterative-minreg", "-disable-machine-licm")
 
 

@@ -261,6 +261,15 @@ __global__ __launch_bounds__(kBlock, PT_ISECT_WAVES) void k_intersect_cand(DevSc
     ring.count = 0u;
     const uint32_t n_chunks = (n + kBlock - 1u) / kBlock;
     bool prev_valid = false;
+#if PT_ISECT_PREFETCH
+    // the next chunk's ray is loaded a trip ahead: the load's latency passes under this trip's arithmetic
+    float4 na = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float2 nc = make_float2(0.0f, 0.0f);
+    if (tid < n) {
+        na = ld_od0(qin, tid);
+        nc = ld_od1(qin, tid);
+    }
+#endif
     for (uint32_t it = 0; it <= n_chunks; ++it) {  // uniform trip count; the last trip only finishes chunk n_chunks - 1
         const uint32_t par = it & 1u;
         const uint32_t i = it * kBlock + tid;
@@ -269,12 +278,23 @@ __global__ __launch_bounds__(kBlock, PT_ISECT_WAVES) void k_intersect_cand(DevSc
         bool ran_batch = false;
         if (it < n_chunks) {
             vec3 o = mk(0.0f, 0.0f, 0.0f), d = o;
+#if PT_ISECT_PREFETCH
+            if (cur_valid) {
+                o = mk(na.x, na.y, na.z);
+                d = mk(na.w, nc.x, nc.y);
+            }
+            if (i + kBlock < n) {
+                na = ld_od0(qin, i + kBlock);
+                nc = ld_od1(qin, i + kBlock);
+            }
+#else
             if (cur_valid) {
                 const float4 a = ld_od0(qin, i);
                 const float2 c = ld_od1(qin, i);
                 o = mk(a.x, a.y, a.z);
                 d = mk(a.w, c.x, c.y);
             }
+#endif
             const uint32_t slot = (par << 6) | lane;
             cand.ray_a[slot] = make_float4(o.x, o.y, o.z, d.x);
             cand.ray_b[slot] = make_float2(d.y, d.z);
