@@ -720,14 +720,18 @@ int plan_pass(const PassPlanIn &in, PassPlan &out, uint64_t *want_next) {
     // k_pass_cand: frames of few samples get more, shorter streams rather than a handful of workgroups per CU slot, each
     // with hundreds of pixels' accumulators and tables (36 B per pixel) in LDS (1024x768 @128: 12 288 streams of 64
     // pixels, not 4 096 of 192)
-    if (in.stack_form && !in.streams && m > 64u) m = 64u;
+    // (round 4, final kernels: with walks up to 128 - 3000x2000 @100, parts of 2^20 pixels: 64 pixels 25.2, 96: 27.1, 128: 27.7, 192: 24.2 G
+    // bounces/s on mesh.json, 1024x768 @128: 26.4 / 27.0 / 26.9 / 23.4; without walks the two frames disagree - 49.0 / 50.4 / 50.6 / 48.5
+    // and 50.4 / 49.5 / 49.0 / 47.9 - and 64 stays)
+    const uint32_t m_few = in.has_bvh ? 128u : 64u;
+    if (in.stack_form && !in.streams && m > m_few) m = m_few;
     // A launch runs its workgroups in rounds of as many as the chip holds (four per CU); a stream's work grows with its m
     // pixels, so a launch takes about ceil(K / resident) x m: among the m within -15 % / +20 % of the tuned size take the
     // one for which that is smallest (cornell 1024x768: m = 21 -> 24, 37 450 streams in 36.6 rounds -> 32 768 in 32.0,
     // 37.3 -> 37.7 G bounces/s).  Not for scenes with walks, whose streams differ too much in length for rounds to show
     // (mesh.json: 24.0 rounds are slower than 25.6).
     // SMALL FRAMES (round 4: the reference's own sizes - its launch configuration is 450x300 @500, .vscode/launch.json).  When
-    // the tuned stream size gives the launch fewer than sixteen rounds of resident workgroups, what a launch takes is
+    // the tuned stream size gives the launch fewer than eight rounds of resident workgroups, what a launch takes is
     // ceil(K / resident) x m to a good approximation, and a last round that is mostly empty costs a whole round: 450x300
     // @500 at the tuned size is 2 756 streams of 49 pixels = 2.7 rounds, mesh.json 21.3 G bounces/s; 4 120 streams of 33
     // pixels = 4.02 rounds: 26.2; 5 493 of 25 = 5.4 rounds: 23.6; 8 240 of 17 = 8.05: 25.0 (cornell.json: 42.1 / 43.0 / 43.2 /
@@ -738,7 +742,9 @@ int plan_pass(const PassPlanIn &in, PassPlan &out, uint64_t *want_next) {
     if (in.stack_form && !in.streams && in.n_cus != 0u && m >= 4u) {
         const uint64_t resident = (uint64_t)in.n_cus * (in.groups_per_cu ? in.groups_per_cu : 4u);
         const uint64_t k_tuned = (npix + m - 1u) / m;
-        if ((k_tuned + resident - 1u) / resident < 16u) {
+        // (fewer than EIGHT rounds - sixteen until the final kernels of round 4: at 12.8 rounds, 3000x2000 @100 in parts of 2^20
+        // pixels, the rule took streams of 20 pixels for the whole rounds' sake and lost 6 % to the 64-pixel streams it replaced)
+        if ((k_tuned + resident - 1u) / resident < 8u) {
             small_frame = true;
             uint32_t best_m = m;
             uint64_t best_cost = ~0ull;
