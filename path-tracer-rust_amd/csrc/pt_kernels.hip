@@ -4,7 +4,11 @@
 //   k_pass_cand                        THE DEFAULT: the whole pass in one launch, candidate scan instead of testing every
 //                                      triangle (pt_device.h), and no levels - every wave of a workgroup (= ray stream: a set
 //                                      of pixels, all samples of the pass) keeps its waiting rays on a stack of its own in
-//                                      global memory, pops 64 or starts 64 primary rays; BVH meshes: walks parked per wave
+//                                      global memory, pops 64 or starts 64 primary rays (consecutive samples of one pixel,
+//                                      the stream's chunks of 64 dealt to the four waves in turn); BVH meshes: walks parked per wave
+// TWO TRANSLATION UNITS.  This file is compiled twice: as it is (every kernel but the instances of k_pass_cand WITHOUT walks and
+// k_intersect_cand), and through pt_kernels_flat.hip with PT_TU_FLAT defined (those instances alone, five waves per SIMD): the
+// two want different instruction scheduling from the back end, and -mllvm options are per compile (Makefile: MLLVM, MLLVM_FLAT).
 // the level-by-level forms (PT_CAND_SCAN=0 / PT_FLAG_NO_BVH / PT_CAND_BVH=0), scenes without BVH meshes:
 //   k_pass                             the whole pass in one launch: per workgroup (= ray stream) the primary rays
 //                                      (render_pixel, mod.rs:812-843), then level by level closest hit
