@@ -141,3 +141,22 @@ def test_bench_two_rank_rehearsal_reports_per_rank_times():
         assert pr[k]["min"] <= pr[k]["mean"] <= pr[k]["max"], (k, pr[k])
     assert abs(2 * pr["ray_bounces"]["mean"] - b["config"]["ray_bounces_per_frame"]) < 1.0  # the ranks' rows make up the frame
     assert pr["render_ms"]["min"] > 0 and b["gather_ms"] is not None
+
+
+@pytest.mark.gpu
+def test_pass_kernel_lds_keeps_its_workgroups_per_cu():
+    """k_pass_cand without walks is built for FIVE workgroups per CU, with walks for four: that holds while a workgroup's LDS stays
+    under what `PT_LDS_PAD` measured (five workgroups of 32 144 B share a CU, five of 32 400 B do not; four of 40 928 B do) - a
+    tenth of the frame rate otherwise, and nothing else would notice.  The library says what it asks for when PT_LDS_PAD is set."""
+    import re
+    import sys
+
+    tool = os.path.join(ptlib.ROOT, "tools", "one_frame.py")
+    for scene, spp, kernel, limit in (("cornell", 683, "k_pass_cand:", 32256), ("cornell", 64, "k_pass_cand:", 32256),
+                                      ("mesh", 512, "k_pass_cand<BVH>:", 40960), ("mesh", 64, "k_pass_cand<BVH>:", 40960)):
+        r = subprocess.run([sys.executable, tool, scene, str(spp)], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, PT_LDS_PAD="0"))
+        assert r.returncode == 0, r.stderr
+        m = re.search(re.escape(kernel) + r" (\d+) bytes of LDS per workgroup", r.stderr)
+        assert m, r.stderr
+        assert int(m.group(1)) <= limit, (scene, spp, m.group(0))
