@@ -2004,12 +2004,12 @@ __device__ __forceinline__ void shade_surface(const Params &F, const PathRay &in
                 const float re = r0 + (1.0f - r0) * c5;
                 const float tr = 1.0f - re;
                 const float p = 0.25f + 0.5f * re;
-                const float rp = re / p;
-                const float tp = tr / (1.0f - p);
                 if (new_depth > 2u) {  // mod.rs:760-774: one of the two, chosen with probability p
+                    // (the reference computes RP = Re / P and TP = Tr / (1 - P) and uses one: the operands are chosen first here,
+                    // and the one division that is needed is the same division)
                     const bool pick_refl = unit_f32(rnd.b) < p;
                     d0 = pick_refl ? refl : tdir;
-                    thr0 = thr * (pick_refl ? rp : tp);
+                    thr0 = thr * ((pick_refl ? re : tr) / (pick_refl ? p : 1.0f - p));
                 } else {  // mod.rs:775-786: both subtrees
                     thr0 = thr * re;
                     d1 = tdir;

@@ -196,7 +196,12 @@ PT_HD void sincos_f32(float y, float *s_out, float *c_out) {
 }
 
 // tent filter of render_pixel (mod.rs:820-830)
-PT_HD float tent(float r) { return r < 1.0f ? f_sqrt(r) - 1.0f : 1.0f - f_sqrt(2.0f - r); }
+// (one square root, of the operand the branch taken would use: the same operations on the same values)
+PT_HD float tent(float r) {
+    const bool lo = r < 1.0f;
+    const float s = f_sqrt(lo ? r : 2.0f - r);
+    return lo ? s - 1.0f : 1.0f - s;
+}
 
 PT_HD float clamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
 
